@@ -1,0 +1,142 @@
+"""The CPU oracle against every golden vector generated from the reference (tests/golden/make_golden.py).
+
+No GPU needed.  This is what 'pins' the oracle: forward, losses, all 18 parameter gradients (sampled
++ checksums), decode, the Langevin sampler and the label maps, on the reference's own outputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import psvae_oracle as O
+from helpers import GOLDEN, assert_close, check_grads_against_fixture, fixture_params, load, step_fixtures
+
+ORACLE_TOL = 2e-5  # oracle vs reference: same ATen kernels, closed-form vs autograd ordering only
+
+
+@pytest.mark.parametrize("path", step_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
+def test_train_step_matches_reference(path):
+    fx = load(path)
+    p = fixture_params(fx)
+    x, eps = torch.from_numpy(fx["x"]), torch.from_numpy(fx["eps"])
+    losses, grads, acts, _ = O.train_step(p, x, eps, float(fx["beta"]), bool(fx["normalize"]), bool(fx["cos"]))
+    assert_close(acts["x_hat"], fx["x_hat"], ORACLE_TOL, "x_hat")
+    assert_close(acts["mu"], fx["mu"], ORACLE_TOL, "mu")
+    assert_close(acts["logvar"], fx["logvar"], ORACLE_TOL, "logvar")
+    assert_close(acts["z"], fx["z"], ORACLE_TOL, "z")
+    for k in ("recon", "kl", "total"):
+        assert abs(float(losses[k]) - float(fx[k])) <= ORACLE_TOL * max(1.0, abs(float(fx[k]))), k
+    check_grads_against_fixture(grads, fx, ORACLE_TOL)
+
+
+@pytest.mark.parametrize("name", ["decode_d256_z64_n33", "decode_d256_z64_n33_norm"])
+def test_decode_matches_reference(name):
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    xh = O.decode(p, torch.from_numpy(fx["z"]), bool(fx["normalize"]))
+    assert_close(xh, fx["x_hat"], ORACLE_TOL, "decode")
+
+
+@pytest.mark.parametrize("name", ["langevin_d256_z64_n8_t5", "langevin_d256_z64_n8_t5_lin"])
+def test_langevin_matches_reference(name):
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    layers = [(torch.from_numpy(fx[f"cls_w{i}"]), torch.from_numpy(fx[f"cls_b{i}"]))
+              for i in range(int(fx["n_cls_layers"]))]
+    z, hist = O.langevin(layers, torch.from_numpy(fx["z0"]), torch.from_numpy(fx["noises"]),
+                         int(fx["target"]), float(fx["step_size"]), float(fx["noise_weight"]))
+    assert_close(torch.stack(hist), fx["hist"], ORACLE_TOL, "langevin history")
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    assert_close(O.decode(p, z), fx["x_hat"], ORACLE_TOL, "langevin decode")
+
+
+def test_label_maps_match_reference():
+    fx = load(os.path.join(GOLDEN, "label_maps.npz"))
+    for s, none, lab in zip(fx["ages"], fx["age_is_none"], fx["age_labels"]):
+        assert O.map_cv_age_to_label(None if none else str(s)) == int(lab)
+    for s, none, cv, vc in zip(fx["genders"], fx["gender_is_none"], fx["cv_gender_labels"], fx["vctk_gender_labels"]):
+        key = None if none else str(s)
+        assert O.map_cv_gender_to_label(key) == int(cv)
+        assert O.map_vctk_gender_to_label(key) == int(vc)
+
+
+def test_backward_closed_form_equals_autograd():
+    """The oracle's closed-form backward vs torch autograd on the oracle's own forward."""
+    D, Z, B = 96, 24, 11
+    p = {k: v.clone().requires_grad_() for k, v in O.init_params(D, Z, 3).items()}
+    torch.manual_seed(5)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    for norm, cos in ((False, False), (True, False), (False, True), (True, True)):
+        acts = O.forward(p, x, eps, norm)
+        _, _, total = O.elbo(acts["x_hat"], x, acts["mu"], acts["logvar"], 0.7, cos)
+        auto = torch.autograd.grad(total, list(p.values()))
+        with torch.no_grad():
+            _, grads, _, _ = O.train_step({k: v.detach() for k, v in p.items()}, x, eps, 0.7, norm, cos)
+        for k, ga in zip(O.PARAM_KEYS, auto):
+            assert_close(grads[k], ga, 2e-5, f"{k} norm={norm} cos={cos}")
+
+
+def test_cond_gather_form_equals_concat_definition():
+    """cfg3 extension (parity unpinned by the reference): gather-add form == explicit one-hot concat."""
+    D, Z, B = 64, 16, 9
+    torch.manual_seed(0)
+    p_cat = O.init_params(D, Z, 1)
+    for blk, n_in in (("encoder_mu", D), ("encoder_sigma", D), ("decoder", Z)):
+        p_cat[f"{blk}.0.weight"] = torch.randn(O.HIDDEN, n_in + O.COND_DIM) * 0.05
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    gender = torch.tensor([0, 1, 2, -1, 0, 1, 2, 2, 0])
+    age = torch.tensor([2, 1, 0, 0, -1, 1, 2, 0, 1])
+    a = O.forward_cond_concat(p_cat, x, eps, gender, age)
+    p, tabs = O.split_cond_params(p_cat, D, Z)
+    b = O.forward_cond(p, tabs, x, eps, gender, age)
+    for k in ("mu", "logvar", "z", "x_hat"):
+        assert_close(b[k], a[k], 1e-5, k)
+    # gradient of the tables vs autograd through the concat definition
+    pc = {k: v.clone().requires_grad_() for k, v in p_cat.items()}
+    a = O.forward_cond_concat(pc, x, eps, gender, age)
+    _, _, total = O.elbo(a["x_hat"], x, a["mu"], a["logvar"], 1.0)
+    total.backward()
+    g_xh, g_mu, g_lv = O.elbo_grads(b["x_hat"], x, b["mu"], b["logvar"], 1.0)
+    grads, tgrads, _ = O.backward_cond(p, tabs, x, b, g_xh, g_mu, g_lv, gender, age)
+    for blk, n_in in (("encoder_mu", D), ("encoder_sigma", D), ("decoder", Z)):
+        gW = pc[f"{blk}.0.weight"].grad
+        assert_close(grads[f"{blk}.0.weight"], gW[:, :n_in], 2e-5, blk)
+        assert_close(tgrads[f"cond.{blk}"], gW[:, n_in:].t(), 2e-5, "table " + blk)
+
+
+def test_philox_known_answer_and_moments():
+    # Random123 known-answer test for philox4x32-10: ctr=key=0 and the all-ones vector
+    r = O.philox4x32_10(np.zeros((1, 4), np.uint32), np.zeros(2, np.uint32))[0]
+    assert [hex(v) for v in r] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    r = O.philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), np.full(2, 0xFFFFFFFF, np.uint32))[0]
+    assert [hex(v) for v in r] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    n = O.philox_normal(1 << 18, seed=1234, offset=77)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
+    assert abs((n ** 3).mean()) < 0.03 and abs((n ** 4).mean() - 3) < 0.1
+    # offset semantics: element e of stream(offset) == element e-4 of stream(offset+1)
+    a = O.philox_normal(64, 9, 10)
+    b = O.philox_normal(60, 9, 11)
+    np.testing.assert_array_equal(a[4:], b)
+
+
+def test_adam_matches_torch():
+    torch.manual_seed(0)
+    w = torch.randn(1000)
+    ref = w.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=0.01)
+    m = torch.zeros_like(w)
+    v = torch.zeros_like(w)
+    cur = w.clone()
+    for step in range(1, 6):
+        g = torch.randn(1000)
+        ref.grad = g.clone()
+        opt.step()
+        cur, m, v = O.adam_step(cur, g, m, v, step, 1e-3, weight_decay=0.01)
+        assert_close(cur, ref.detach(), 1e-6, f"adam step {step}")
+    sched_p = torch.nn.Parameter(torch.zeros(1))
+    o2 = torch.optim.Adam([sched_p], lr=0.01)
+    s = torch.optim.lr_scheduler.CosineAnnealingLR(o2, T_max=10, eta_min=1e-4)
+    for ep in range(10):
+        assert abs(o2.param_groups[0]["lr"] - O.cosine_lr(0.01, ep, 10, 1e-4)) < 1e-9
+        o2.step()
+        s.step()
