@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: speaker-embeddings/sec for one VAE training pass (forward + ELBO + backward
+[+ RCCL gradient all-reduce when N > 1]) at BASELINE.json's config 2: d_in=256, z=64, batch=1024 per
+GPU, fp32, synthetic N(0,1) embeddings already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  `value` = whole-job embeddings/s; weak scaling (1024 rows per GPU).
+`roofline`: algorithmic FLOPs of the step (7,143,424 FLOP/embedding at cfg2) over the
+step duration measured with HIP events on the launch stream, against the fp32 MFMA peak.
+`cpu_baseline`: the CPU oracle (a port of the reference's math, oracle/psvae_oracle.py) timed on
+this box's host cores over a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+H = 512
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def flop_per_embedding(D: int, Z: int) -> int:
+    fwd = 2 * (D * H + H * H + H * Z) + (Z * H + H * H + H * D)
+    bwd = 2 * fwd - 2 * D * H
+    return 2 * (fwd + bwd)
+
+
+def cpu_baseline(D, Z, B, steps=40, warmup=3):
+    """oracle fwd+ELBO+bwd on the host cores (checker code used as the timed CPU port)."""
+    from oracle import psvae_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = O.init_params(D, Z, 0)
+    torch.manual_seed(0)
+    x = torch.randn(B, D)
+    eps = torch.randn(B, Z)
+    for _ in range(warmup):
+        O.train_step(p, x, eps, 1.0)
+    t0 = time.perf_counter()
+    n = 0
+    while n < steps and time.perf_counter() - t0 < 20.0:
+        O.train_step(p, x, eps, 1.0)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 1), "unit": "speaker-embeddings/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} steps of fwd+ELBO+bwd at B={B}, D={D}, Z={Z} (oracle, torch-CPU fp32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--input-dim", type=int, default=256)
+    ap.add_argument("--latent-dim", type=int, default=64)
+    ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
+    ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    from pseudo_speaker_vae_amd import build
+    if rank == 0:
+        build.build(verbose=False)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+        dist.barrier()
+
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    D, Z, B = args.input_dim, args.latent_dim, args.batch
+    eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=pg)
+    g = torch.Generator().manual_seed(1234 + rank)  # each rank its own shard of synthetic rows
+    x = torch.randn(B, D, generator=g).to(dev)
+
+    mode = args.mode
+    if mode == "auto":
+        mode = "graph" if world == 1 else "eager"
+    if mode == "graph":
+        eng.capture(x)
+
+        def step():
+            eng.replay()
+            if args.with_adam:
+                eng.optimizer_step()
+    else:
+        def step():
+            eng.forward_backward(x)
+            if args.with_adam:
+                eng.optimizer_step()
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = t.tolist()
+    loss = eng.loss3.detach().cpu().tolist()
+
+    if rank == 0:
+        fpe = flop_per_embedding(D, Z)
+        step_s_dev = dev_ms / 1e3 / args.steps
+        achieved = fpe * B / step_s_dev / 1e12  # per GPU, over the HIP-event duration of the step
+        out = {
+            "metric": "speaker-embeddings/sec (fwd+bwd)",
+            "value": round(B * world * args.steps / wall, 1),
+            "unit": "speaker-embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: VAE fwd+ELBO+bwd{'+Adam' if args.with_adam else ''}"
+                                   f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
+                                   f"batch={B}/GPU, global_batch={B * world}, fp32",
+                       "launch": mode, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5)},
+            "loss": [round(v, 6) for v in loss],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(D, Z, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/* psvae.h -- C ABI of libpsvae_hip.so: the MI355X (gfx950) implementation of the pseudo-speaker VAE
+ * hot path.  Plain C types only (device pointers as typed pointers, sizes as int64_t, hipStream_t
+ * as void*).  The reference (nmehlman/pseudo_speaker_VAE) is pure Python and has no FFI of its own;
+ * each entry point below names the reference interface (file:line under /root/reference) it stands
+ * in for, and INTEGRATION.md shows the ctypes binding a maintainer adds to ps_vae/model.py.
+ *
+ * Conventions
+ *   - every buffer is caller-owned device memory (fp32, row-major, contiguous unless stated);
+ *     the library allocates nothing persistent and keeps no pointer after a call returns
+ *     (exception: the explicit psvae_plan_* handle, which owns a captured hipGraph);
+ *   - all work is enqueued on `stream`; no call synchronises the device or the host;
+ *   - return 0 on success, <0 for an argument error detected before any launch, >0 = hipError_t;
+ *     psvae_strerror() maps both; no C++ exception crosses the boundary;
+ *   - weights are nn.Linear layout [out, in]; hidden width is PSVAE_HIDDEN (model.py:15-35).
+ */
+#ifndef PSVAE_H
+#define PSVAE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSVAE_ABI_VERSION 1
+#define PSVAE_HIDDEN 512
+#define PSVAE_NPARAM 18
+#define PSVAE_COND_DIM 6 /* onehot3(gender) || onehot3(age), SURVEY.md section 8a row A9 */
+
+/* flags */
+#define PSVAE_NORMALIZE_DECODER 1u /* model.py:60-61, 67-68 */
+#define PSVAE_COS_LOSS 2u          /* lightning.py:110-111 */
+
+/* backward phases (psvae_backward_f32 `phases`): decoder grads are complete after phase 1, so a
+ * data-parallel caller can start their all-reduce while phase 2 (both encoders) still runs */
+#define PSVAE_PHASE_DECODER 1u
+#define PSVAE_PHASE_ENCODER 2u
+#define PSVAE_PHASE_ALL 3u
+
+/* error codes (<0) */
+#define PSVAE_OK 0
+#define PSVAE_ERR_NULL -1   /* a required pointer is NULL */
+#define PSVAE_ERR_SHAPE -2  /* non-positive or unsupported dimension */
+#define PSVAE_ERR_ALIGN -3  /* a pointer is not 16-byte aligned */
+#define PSVAE_ERR_ARG -4    /* bad enum / flag / phase value */
+#define PSVAE_ERR_STATE -5  /* plan misuse */
+
+typedef struct psvae_dims {
+    int64_t B; /* batch rows */
+    int64_t D; /* input_dim  (model.py:8) */
+    int64_t Z; /* latent_dim (model.py:8) */
+} psvae_dims;
+
+/* The 18 parameter tensors in creation order (model.py:14-36):
+ *  [0..5]  encoder_mu.{0,2,4}.{weight,bias}    W[512,D] b[512] W[512,512] b[512] W[Z,512] b[Z]
+ *  [6..11] encoder_sigma.{0,2,4}.{weight,bias} same shapes
+ *  [12..17] decoder.{0,2,4}.{weight,bias}      W[512,Z] b[512] W[512,512] b[512] W[D,512] b[D] */
+typedef struct psvae_params {
+    const float* p[PSVAE_NPARAM];
+} psvae_params;
+
+typedef struct psvae_grads {
+    float* g[PSVAE_NPARAM]; /* same order/shapes; OVERWRITTEN, never accumulated */
+} psvae_grads;
+
+/* Optional conditional tables (build-defined cfg3 extension; NULL pointers = unconditional).
+ * tab[k] is [6, 512]: row j is the first-layer weight column of one-hot slot j. */
+typedef struct psvae_cond {
+    const float* tab[3];   /* encoder_mu, encoder_sigma, decoder */
+    float* gtab[3];        /* their gradients (backward only; may be NULL in forward) */
+    const int32_t* gender; /* [B] in {-1,0,1,2}; utils.py:105-120 */
+    const int32_t* age;    /* [B] in {-1,0,1,2}; utils.py:82-103 */
+} psvae_cond;
+
+/* Activations saved by forward for backward (caller-owned). */
+typedef struct psvae_acts {
+    float* h1m; /* [B,512] post-ReLU, encoder_mu.1 */
+    float* h2m; /* [B,512] post-ReLU, encoder_mu.3 */
+    float* h1s; /* [B,512] encoder_sigma.1 */
+    float* h2s; /* [B,512] encoder_sigma.3 */
+    float* eps; /* [B,Z] the N(0,1) draw of model.py:57 */
+    float* z;   /* [B,Z] */
+    float* d1;  /* [B,512] decoder.1 */
+    float* d2;  /* [B,512] decoder.3 */
+    float* ynorm; /* [B] max(||y||,1e-12); only with PSVAE_NORMALIZE_DECODER, else may be NULL */
+} psvae_acts;
+
+int psvae_version(void);
+const char* psvae_strerror(int code);
+
+/* bytes of scratch the calls below need for a batch of B rows (any call; take the max over calls) */
+size_t psvae_scratch_bytes(const psvae_dims* dims);
+
+/* Test hook for the epsilon generator: n standard normals, Philox4x32-10 + Box-Muller; element e
+ * comes from Philox block (offset + e/4), key = seed.  Replaces torch.randn_like (model.py:57). */
+int psvae_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* VAEModel.forward (model.py:38-63).  eps_in != NULL injects the normal draw (parity tests);
+ * eps_in == NULL draws it from Philox(seed, offset) -- either way it is written to acts->eps.
+ * rng_state (nullable, device, 2 x uint64 {seed, offset}) overrides the host (seed, offset) and is
+ * advanced on the device by the Philox blocks consumed: a captured hipGraph then draws fresh noise
+ * on every replay.  Outputs x_hat[B,D], mu[B,Z], logvar[B,Z] (the reference's "log_sigma" is a
+ * log-variance). */
+int psvae_forward_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
+                      const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,
+                      uint64_t seed, uint64_t offset, uint64_t* rng_state /* nullable */,
+                      const psvae_acts* acts, float* x_hat, float* mu, float* logvar, void* scratch,
+                      uint32_t flags, void* stream);
+
+/* ELBO of training_step (lightning.py:110-124): loss3 = {total, recon, kl} (device, 3 floats).
+ * recon = mean((x_hat-x)^2)/10, or mean_b(1-cos) with PSVAE_COS_LOSS; kl = -0.5 mean_b sum_j(..). */
+int psvae_elbo_f32(const psvae_dims* dims, const float* x, const float* x_hat, const float* mu,
+                   const float* logvar, float beta, float* loss3, void* scratch, uint32_t flags,
+                   void* stream);
+
+/* Backward of forward (+ optionally of the ELBO): overwrites the 18 gradients.
+ *   g_xhat / g_mu / g_logvar: upstream gradients of the three forward outputs (each nullable = 0);
+ *   elbo != 0 adds grad_loss * d(total)/d(.) of psvae_elbo_f32 (grad_loss: device scalar, NULL = 1);
+ *   g_x (nullable): gradient w.r.t. the input x (the reference never needs it; autograd callers may).
+ * Stands in for loss.backward() after lightning.py:131. */
+int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
+                       const psvae_cond* cond /* nullable */, const psvae_acts* acts, const float* x_hat,
+                       const float* mu, const float* logvar, const float* g_xhat, const float* g_mu,
+                       const float* g_logvar, int elbo, float beta, const float* grad_loss,
+                       const psvae_grads* grads, float* g_x, void* scratch, uint32_t flags,
+                       uint32_t phases, void* stream);
+
+/* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
+ * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
+size_t psvae_decode_scratch_bytes(int64_t N);
+int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6,
+                     const float* cond_tab /* nullable [6,512] */, const int32_t* gender,
+                     const int32_t* age, float* x_hat, void* scratch, uint32_t flags, void* stream);
+
+/* Test / bench hook: one fp32 MFMA GEMM of the kind the path is built from.
+ *   kind 0 (NT): C[M,N] = A[M,K] B[N,K]^T     (forward Linear, model.py:15)
+ *   kind 1 (NN): C[M,N] = A[M,K] B[K,N]       (dgrad)
+ *   kind 2 (TN): C[M,N] = A[K,M]^T B[K,N]     (wgrad; colsum != NULL also writes sum_k A[k,:])
+ *   epi 0 none, 1 +bias[N], 2 relu(+bias), 3 * (mask[M,N] > 0).  tile: 0 = auto, else (TM<<4)|TN. */
+int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask,
+                   float* colsum, int epi, int tile, void* stream);
+
+/* Fused multi-tensor Adam on flat buffers (lightning.py:205; torch.optim.Adam semantics).
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce(sum)).  Hyper-parameters
+ * are doubles so that 1-beta etc. round exactly as torch's (python-float) arithmetic does. */
+int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        double grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSVAE_H */

@@ -1,0 +1,158 @@
+"""ctypes binding of libpsvae_hip.so (include/psvae.h).  Thin: pointers in, error codes out.
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback anywhere in the product path.
+A missing / unloadable library raises at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libpsvae_hip.so")
+
+NPARAM = 18
+HIDDEN = 512
+COND_DIM = 6
+NORMALIZE_DECODER = 1
+COS_LOSS = 2
+PHASE_DECODER, PHASE_ENCODER, PHASE_ALL = 1, 2, 3
+ABI_VERSION = 1
+
+# every symbol include/psvae.h declares (tests check the .so exports each of them)
+SYMBOLS = (
+    "psvae_version", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
+    "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_decode_scratch_bytes",
+    "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32",
+)
+
+
+class Dims(C.Structure):
+    _fields_ = [("B", C.c_int64), ("D", C.c_int64), ("Z", C.c_int64)]
+
+
+class Params(C.Structure):
+    _fields_ = [("p", C.c_void_p * NPARAM)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("g", C.c_void_p * NPARAM)]
+
+
+class Cond(C.Structure):
+    _fields_ = [("tab", C.c_void_p * 3), ("gtab", C.c_void_p * 3), ("gender", C.c_void_p), ("age", C.c_void_p)]
+
+
+ACT_FIELDS = ("h1m", "h2m", "h1s", "h2s", "eps", "z", "d1", "d2", "ynorm")
+
+
+class Acts(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ACT_FIELDS]
+
+
+class PsvaeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsvaeError(
+            f"{LIB_PATH} is missing: build it with `python -m pseudo_speaker_vae_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    L.psvae_version.restype = C.c_int
+    L.psvae_strerror.restype = C.c_char_p
+    L.psvae_strerror.argtypes = [C.c_int]
+    L.psvae_scratch_bytes.restype = C.c_size_t
+    L.psvae_scratch_bytes.argtypes = [C.POINTER(Dims)]
+    L.psvae_decode_scratch_bytes.restype = C.c_size_t
+    L.psvae_decode_scratch_bytes.argtypes = [C.c_int64]
+    vp, u64, i64, u32, f32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_float
+    L.psvae_philox_normal_f32.argtypes = [vp, i64, u64, u64, vp]
+    L.psvae_forward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), vp, u64, u64, vp,
+                                    C.POINTER(Acts), vp, vp, vp, vp, u32, vp]
+    L.psvae_elbo_f32.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, f32, vp, vp, u32, vp]
+    L.psvae_backward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), C.POINTER(Acts),
+                                     vp, vp, vp, vp, vp, vp, C.c_int, f32, vp, C.POINTER(Grads), vp, vp, u32, u32, vp]
+    L.psvae_decode_f32.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp, u32, vp]
+    L.psvae_gemm_f32.argtypes = [C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp, vp, C.c_int, C.c_int, vp]
+    f64 = C.c_double
+    L.psvae_adam_step_f32.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64, f64, vp]
+    for fn in ("psvae_philox_normal_f32", "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32",
+               "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32"):
+        getattr(L, fn).restype = C.c_int
+    if L.psvae_version() != ABI_VERSION:
+        raise PsvaeError(f"libpsvae_hip.so ABI {L.psvae_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        raise PsvaeError(f"{what}: {lib().psvae_strerror(code).decode()} (code {code})")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, None for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PsvaeError("psvae kernels need tensors on the GPU (cuda:N); got a CPU tensor and there is no CPU path")
+    if not t.is_contiguous():
+        raise PsvaeError("psvae kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_params(tensors: Sequence[torch.Tensor]) -> Params:
+    assert len(tensors) == NPARAM
+    p = Params()
+    for i, t in enumerate(tensors):
+        if t.dtype != torch.float32:
+            raise PsvaeError("parameters must be float32")
+        p.p[i] = ptr(t)
+    return p
+
+
+def make_grads(tensors: Sequence[torch.Tensor]) -> Grads:
+    assert len(tensors) == NPARAM
+    g = Grads()
+    for i, t in enumerate(tensors):
+        g.g[i] = ptr(t)
+    return g
+
+
+def make_acts(d: dict) -> Acts:
+    a = Acts()
+    for n in ACT_FIELDS:
+        setattr(a, n, ptr(d.get(n)))
+    return a
+
+
+def make_cond(tabs, gtabs, gender, age) -> Optional[Cond]:
+    if tabs is None:
+        return None
+    c = Cond()
+    for i in range(3):
+        c.tab[i] = ptr(tabs[i])
+        c.gtab[i] = ptr(gtabs[i]) if gtabs is not None else None
+    c.gender = ptr(gender)
+    c.age = ptr(age)
+    return c
+
+
+def scratch_bytes(B: int, D: int, Z: int) -> int:
+    return int(lib().psvae_scratch_bytes(C.byref(Dims(B, D, Z))))

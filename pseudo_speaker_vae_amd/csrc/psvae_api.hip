@@ -1,0 +1,341 @@
+// extern "C" entry points of libpsvae_hip.so (declared in include/psvae.h): argument checks, then the
+// launch sequence of the VAE hot path on the caller's stream.  No allocation, no synchronisation.
+#include <stdio.h>
+#include <string.h>
+
+#include "psvae_common.h"
+
+using namespace psvae;
+
+namespace {
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_dims(const psvae_dims* d) {
+    if (!d) return PSVAE_ERR_NULL;
+    if (d->B <= 0 || d->D <= 0 || d->Z <= 0) return PSVAE_ERR_SHAPE;
+    if (d->B > (1 << 24) || d->D > (1 << 16) || d->Z > (1 << 16)) return PSVAE_ERR_SHAPE;
+    return 0;
+}
+
+// scratch carve (floats), identical for every call so phases can share it
+struct Scratch {
+    float *y, *gy, *dd2, *dd1, *gz, *gmu, *glv, *dh2m, *dh2s, *dh1m, *dh1s, *partials;
+    size_t bytes;
+};
+
+Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
+    Scratch s{};
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    s.y = take((size_t)B * D);
+    s.gy = take((size_t)B * D);
+    s.dd2 = take((size_t)B * H);
+    s.dd1 = take((size_t)B * H);
+    s.gz = take((size_t)B * Z);
+    s.gmu = take((size_t)B * Z);
+    s.glv = take((size_t)B * Z);
+    s.dh2m = take((size_t)B * H);
+    s.dh2s = take((size_t)B * H);
+    s.dh1m = take((size_t)B * H);
+    s.dh1s = take((size_t)B * H);
+    s.partials = take(2 * 1024);
+    s.bytes = off;
+    return s;
+}
+
+#define RET_IF(e)                            \
+    do {                                     \
+        hipError_t _e = (e);                 \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+inline void add(GemmBatch& b, const GemmDesc& d) { b.d[b.n++] = d; }
+
+inline void set_cond(GemmDesc& d, const psvae_cond* c, int which) {
+    if (!c || !c->tab[which]) return;
+    d.gender = c->gender;
+    d.age = c->age;
+    d.ctab = c->tab[which];
+}
+
+}  // namespace
+
+extern "C" {
+
+int psvae_version(void) { return PSVAE_ABI_VERSION; }
+
+const char* psvae_strerror(int code) {
+    switch (code) {
+        case PSVAE_OK: return "ok";
+        case PSVAE_ERR_NULL: return "psvae: a required pointer is NULL";
+        case PSVAE_ERR_SHAPE: return "psvae: non-positive or unsupported dimension";
+        case PSVAE_ERR_ALIGN: return "psvae: pointer is not 16-byte aligned";
+        case PSVAE_ERR_ARG: return "psvae: bad enum / flag / phase argument";
+        case PSVAE_ERR_STATE: return "psvae: plan used in the wrong state";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "psvae: unknown error";
+    }
+}
+
+size_t psvae_scratch_bytes(const psvae_dims* dims) {
+    if (check_dims(dims)) return 0;
+    return carve(nullptr, dims->B, dims->D, dims->Z).bytes;
+}
+
+int psvae_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out) return PSVAE_ERR_NULL;
+    if (n < 0) return PSVAE_ERR_SHAPE;
+    RET_IF(launch_philox_normal(out, n, seed, offset, (hipStream_t)stream));
+    return 0;
+}
+
+int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                   int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask, float* colsum, int epi, int tile,
+                   void* stream) {
+    if (!A || !B || !C) return PSVAE_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return PSVAE_ERR_SHAPE;
+    if (kind < 0 || kind > 2 || epi < 0 || epi > 4) return PSVAE_ERR_ARG;
+    if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_MASK) && !bias_or_mask) return PSVAE_ERR_NULL;
+    if (tile != 0) {
+        const int TM = tile >> 4, TN = tile & 15;
+        if (!((TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4))) return PSVAE_ERR_ARG;
+        if (TM * TN == 4 && TM != TN) return PSVAE_ERR_ARG;  // 4x1 / 1x4 not instantiated
+    }
+    GemmBatch b{};
+    add(b, make_desc(kind, (int)M, (int)N, (int)K, A, (int)lda, B, (int)ldb, C, (int)ldc, epi, bias_or_mask,
+                     kind == GK_TN ? colsum : nullptr));
+    RET_IF(launch_gemm_batch(b, tile, (hipStream_t)stream));
+    return 0;
+}
+
+int psvae_forward_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                      const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, const psvae_acts* acts,
+                      float* x_hat, float* mu, float* logvar, void* scratch, uint32_t flags, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!x || !params || !acts || !x_hat || !mu || !logvar) return PSVAE_ERR_NULL;
+    for (int i = 0; i < PSVAE_NPARAM; ++i)
+        if (!params->p[i]) return PSVAE_ERR_NULL;
+    if (!acts->h1m || !acts->h2m || !acts->h1s || !acts->h2s || !acts->eps || !acts->z || !acts->d1 || !acts->d2)
+        return PSVAE_ERR_NULL;
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
+    if (normalize && (!acts->ynorm || !scratch)) return PSVAE_ERR_NULL;
+    if (flags & ~(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS)) return PSVAE_ERR_ARG;
+    if (cond && cond->tab[0] && (!cond->gender || !cond->age || !cond->tab[1] || !cond->tab[2])) return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* P = params->p;
+    Scratch sc = carve(scratch, B, D, Z);
+
+    {  // encoder layer 1 (model.py:15,23): both encoders in one launch
+        GemmBatch b{};
+        GemmDesc dm = make_desc(GK_NT, B, H, D, x, D, P[0], D, acts->h1m, H, EPI_BIAS_RELU, P[1]);
+        GemmDesc ds = make_desc(GK_NT, B, H, D, x, D, P[6], D, acts->h1s, H, EPI_BIAS_RELU, P[7]);
+        set_cond(dm, cond, 0);
+        set_cond(ds, cond, 1);
+        add(b, dm); add(b, ds);
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    {  // encoder layer 2 (model.py:17,25)
+        GemmBatch b{};
+        add(b, make_desc(GK_NT, B, H, H, acts->h1m, H, P[2], H, acts->h2m, H, EPI_BIAS_RELU, P[3]));
+        add(b, make_desc(GK_NT, B, H, H, acts->h1s, H, P[8], H, acts->h2s, H, EPI_BIAS_RELU, P[9]));
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    {  // encoder layer 3 -> mu, logvar (model.py:19,27)
+        GemmBatch b{};
+        add(b, make_desc(GK_NT, B, Z, H, acts->h2m, H, P[4], H, mu, Z, EPI_BIAS, P[5]));
+        add(b, make_desc(GK_NT, B, Z, H, acts->h2s, H, P[10], H, logvar, Z, EPI_BIAS, P[11]));
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    // reparameterise (model.py:56-57)
+    RET_IF(launch_reparam(mu, logvar, eps_in, seed, offset, rng_state, acts->eps, acts->z, (int64_t)B * Z, s));
+    {  // decoder (model.py:31-35)
+        GemmBatch b{};
+        GemmDesc d1 = make_desc(GK_NT, B, H, Z, acts->z, Z, P[12], Z, acts->d1, H, EPI_BIAS_RELU, P[13]);
+        set_cond(d1, cond, 2);
+        add(b, d1);
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    {
+        GemmBatch b{};
+        add(b, make_desc(GK_NT, B, H, H, acts->d1, H, P[14], H, acts->d2, H, EPI_BIAS_RELU, P[15]));
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    {
+        GemmBatch b{};
+        add(b, make_desc(GK_NT, B, D, H, acts->d2, H, P[16], H, normalize ? sc.y : x_hat, D, EPI_BIAS, P[17]));
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    if (normalize) RET_IF(launch_normalize_rows(sc.y, x_hat, acts->ynorm, B, D, s));  // model.py:60-61
+    return 0;
+}
+
+int psvae_elbo_f32(const psvae_dims* dims, const float* x, const float* x_hat, const float* mu, const float* logvar,
+                   float beta, float* loss3, void* scratch, uint32_t flags, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!x || !x_hat || !mu || !logvar || !loss3 || !scratch) return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    Scratch sc = carve(scratch, B, D, Z);
+    RET_IF(launch_elbo_loss(x, x_hat, mu, logvar, B, D, Z, beta, flags & PSVAE_COS_LOSS, sc.partials, loss3,
+                            (hipStream_t)stream));
+    return 0;
+}
+
+int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                       const psvae_acts* acts, const float* x_hat, const float* mu, const float* logvar,
+                       const float* g_xhat, const float* g_mu, const float* g_logvar, int elbo, float beta,
+                       const float* grad_loss, const psvae_grads* grads, float* g_x, void* scratch, uint32_t flags,
+                       uint32_t phases, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!x || !params || !acts || !x_hat || !mu || !logvar || !grads || !scratch) return PSVAE_ERR_NULL;
+    if (phases == 0 || (phases & ~PSVAE_PHASE_ALL)) return PSVAE_ERR_ARG;
+    for (int i = 0; i < PSVAE_NPARAM; ++i)
+        if (!params->p[i] || !grads->g[i]) return PSVAE_ERR_NULL;
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
+    if (normalize && !acts->ynorm) return PSVAE_ERR_NULL;
+    const bool has_cond = cond && cond->tab[0];
+    if (has_cond && (!cond->gtab[0] || !cond->gtab[1] || !cond->gtab[2])) return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* P = params->p;
+    float* const* G = grads->g;
+    Scratch sc = carve(scratch, B, D, Z);
+
+    if (phases & PSVAE_PHASE_DECODER) {
+        const float* gy;
+        if (!elbo && !normalize && g_xhat) {
+            gy = g_xhat;  // nothing to add: use the upstream gradient in place
+        } else {
+            RET_IF(launch_recon_grad(x, x_hat, acts->ynorm, g_xhat, elbo, flags & PSVAE_COS_LOSS, normalize, grad_loss,
+                                     sc.gy, B, D, s));
+            gy = sc.gy;
+        }
+        {  // decoder.4: dW = gy^T d2, db = colsum(gy); dd2 = (gy W) * [d2 > 0]
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, D, H, B, gy, D, acts->d2, H, G[16], H, EPI_NONE, nullptr, G[17]));
+            add(b, make_desc(GK_NN, B, H, D, gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {  // decoder.2
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, H, B, sc.dd2, H, acts->d1, H, G[14], H, EPI_NONE, nullptr, G[15]));
+            add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {  // decoder.0: dW = dd1^T z ; g_z = dd1 W
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, Z, B, sc.dd1, H, acts->z, Z, G[12], Z, EPI_NONE, nullptr, G[13]));
+            add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        RET_IF(launch_reparam_bwd(sc.gz, mu, logvar, acts->eps, g_mu, g_logvar, elbo, beta, grad_loss, sc.gmu, sc.glv,
+                                  B, Z, s));
+        if (has_cond) {
+            const float* dy[1] = {sc.dd1};
+            float* gt[1] = {cond->gtab[2]};
+            RET_IF(launch_cond_colsum(dy, gt, 1, cond->gender, cond->age, B, H, s));
+        }
+    }
+    if (phases & PSVAE_PHASE_ENCODER) {
+        {  // encoder_*.4
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, Z, H, B, sc.gmu, Z, acts->h2m, H, G[4], H, EPI_NONE, nullptr, G[5]));
+            add(b, make_desc(GK_TN, Z, H, B, sc.glv, Z, acts->h2s, H, G[10], H, EPI_NONE, nullptr, G[11]));
+            add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
+            add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {  // encoder_*.2
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, H, B, sc.dh2m, H, acts->h1m, H, G[2], H, EPI_NONE, nullptr, G[3]));
+            add(b, make_desc(GK_TN, H, H, B, sc.dh2s, H, acts->h1s, H, G[8], H, EPI_NONE, nullptr, G[9]));
+            add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
+            add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {  // encoder_*.0 (x needs no gradient in the reference: no dgrad)
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, D, B, sc.dh1m, H, x, D, G[0], D, EPI_NONE, nullptr, G[1]));
+            add(b, make_desc(GK_TN, H, D, B, sc.dh1s, H, x, D, G[6], D, EPI_NONE, nullptr, G[7]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        if (has_cond) {
+            const float* dy[2] = {sc.dh1m, sc.dh1s};
+            float* gt[2] = {cond->gtab[0], cond->gtab[1]};
+            RET_IF(launch_cond_colsum(dy, gt, 2, cond->gender, cond->age, B, H, s));
+        }
+        if (g_x) {  // optional: d/dx = dh1m W1m + dh1s W1s (two dependent launches: the second accumulates)
+            GemmBatch b1{};
+            add(b1, make_desc(GK_NN, B, D, H, sc.dh1m, H, P[0], D, g_x, D, EPI_NONE, nullptr));
+            RET_IF(launch_gemm_batch(b1, 0, s));
+            GemmBatch b2{};
+            add(b2, make_desc(GK_NN, B, D, H, sc.dh1s, H, P[6], D, g_x, D, EPI_ACCUM, nullptr));
+            RET_IF(launch_gemm_batch(b2, 0, s));
+        }
+    }
+    return 0;
+}
+
+static const int64_t DECODE_CHUNK = 65536;
+
+size_t psvae_decode_scratch_bytes(int64_t N) {
+    if (N <= 0) return 0;
+    const int64_t c = N < DECODE_CHUNK ? N : DECODE_CHUNK;
+    return 2 * align_up((size_t)c * H * sizeof(float), 256) + align_up((size_t)c * sizeof(float), 256);
+}
+
+int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6, const float* cond_tab,
+                     const int32_t* gender, const int32_t* age, float* x_hat, void* scratch, uint32_t flags,
+                     void* stream) {
+    if (N <= 0 || D <= 0 || Z <= 0) return PSVAE_ERR_SHAPE;
+    if (!z || !dec6 || !x_hat || !scratch) return PSVAE_ERR_NULL;
+    for (int i = 0; i < 6; ++i)
+        if (!dec6[i]) return PSVAE_ERR_NULL;
+    if (cond_tab && (!gender || !age)) return PSVAE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
+    const int64_t c = N < DECODE_CHUNK ? N : DECODE_CHUNK;
+    float* d1 = reinterpret_cast<float*>(scratch);
+    float* d2 = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + align_up((size_t)c * H * sizeof(float), 256));
+    float* yn = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 2 * align_up((size_t)c * H * sizeof(float), 256));
+    for (int64_t r0 = 0; r0 < N; r0 += c) {
+        const int n = (int)((N - r0) < c ? (N - r0) : c);
+        {
+            GemmBatch b{};
+            GemmDesc d = make_desc(GK_NT, n, H, (int)Z, z + r0 * Z, (int)Z, dec6[0], (int)Z, d1, H, EPI_BIAS_RELU, dec6[1]);
+            if (cond_tab) { d.ctab = cond_tab; d.gender = gender + r0; d.age = age + r0; }
+            add(b, d);
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, n, H, H, d1, H, dec6[2], H, d2, H, EPI_BIAS_RELU, dec6[3]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            // with normalisation the un-normalised rows go to x_hat first and are normalised in place
+            add(b, make_desc(GK_NT, n, (int)D, H, d2, H, dec6[4], H, x_hat + r0 * D, (int)D, EPI_BIAS, dec6[5]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        if (normalize) RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+    }
+    return 0;
+}
+
+int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                        double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                        void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return PSVAE_ERR_NULL;
+    if (n < 0 || step < 1) return PSVAE_ERR_SHAPE;
+    RET_IF(launch_adam(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                       (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libpsvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/psvae.h"
+
+namespace psvae {
+
+constexpr int H = PSVAE_HIDDEN;
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- grouped fp32 MFMA GEMM -------------------------------------------------------------------
+enum GemmKind { GK_NT = 0, GK_NN = 1, GK_TN = 2 };
+enum GemmEpi {
+    EPI_NONE = 0,
+    EPI_BIAS = 1,       // C = acc + bias[col]
+    EPI_BIAS_RELU = 2,  // C = relu(acc + bias[col])
+    EPI_MASK = 3,       // C = acc * (mask[row][col] > 0)     (ReLU backward, mask = saved activation)
+    EPI_ACCUM = 4,      // C += acc                            (second dgrad into the same buffer)
+};
+
+struct GemmDesc {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* aux;      // bias[N] (EPI_BIAS*) or mask[M,ldc] (EPI_MASK)
+    float* colsum;         // GK_TN only, nullable: colsum[m] = sum_k A[k][m]  (bias gradient)
+    const float* ctab;     // nullable: conditional table [6,N] added per row in EPI_BIAS* (cfg3)
+    const int32_t* gender; // [rows] labels for ctab
+    const int32_t* age;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int kind, epi;
+    int tiles_m, tiles_n;
+    int tile_begin;  // first linear tile of this problem inside the launch
+};
+
+constexpr int MAX_GROUP = 6;
+struct GemmBatch {
+    GemmDesc d[MAX_GROUP];
+    int n;
+    int total_tiles;
+};
+
+// tile = (TM << 4) | TN with TM,TN in {1,2,4}: workgroup tile (32*TM) x (32*TN), 4 waves as 2x2.
+// tile == 0 picks one from the problem sizes (see pick_tile).
+int pick_tile(const GemmBatch& b);
+void finalize_batch(GemmBatch& b, int tile);
+hipError_t launch_gemm_batch(GemmBatch& b, int tile, hipStream_t stream);
+
+inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, int epi, const float* aux, float* colsum = nullptr) {
+    GemmDesc d{};
+    d.A = A; d.B = B; d.C = C; d.aux = aux; d.colsum = colsum;
+    d.ctab = nullptr; d.gender = nullptr; d.age = nullptr;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.kind = kind; d.epi = epi;
+    return d;
+}
+
+// ---- elementwise / row kernels (elementwise.hip) ------------------------------------------------
+hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+// z = mu + exp(0.5 lv) * eps ; eps from eps_in or Philox; writes eps_out, z
+// rng (nullable, device {seed, offset}) overrides seed/offset and is advanced by ceil(n/4) afterwards
+hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in, uint64_t seed,
+                          uint64_t offset, uint64_t* rng, float* eps_out, float* z, int64_t n, hipStream_t s);
+// row L2 normalise: xh = y / max(||y||, 1e-12), ynorm = that max
+hipError_t launch_normalize_rows(const float* y, float* xh, float* ynorm, int B, int D, hipStream_t s);
+// loss3 = {total, recon, kl}
+hipError_t launch_elbo_loss(const float* x, const float* xh, const float* mu, const float* lv, int B, int D,
+                            int Z, float beta, bool cos_loss, float* partials, float* loss3, hipStream_t s);
+int elbo_partial_blocks(int B);
+// g_y = d/dy [upstream g_xhat + go * recon term], through the optional row normalisation
+hipError_t launch_recon_grad(const float* x, const float* xh, const float* ynorm, const float* g_xhat,
+                             bool elbo, bool cos_loss, bool normalize, const float* go, float* g_y, int B,
+                             int D, hipStream_t s);
+// g_mu = g_z + [g_mu_up] + go*beta*mu/B ; g_lv = g_z*eps*0.5*exp(0.5 lv) + [g_lv_up] + go*beta*(e^lv-1)/(2B)
+hipError_t launch_reparam_bwd(const float* g_z, const float* mu, const float* lv, const float* eps,
+                              const float* g_mu_up, const float* g_lv_up, bool elbo, float beta,
+                              const float* go, float* g_mu, float* g_lv, int B, int Z, hipStream_t s);
+// gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
+hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
+                              const int32_t* age, int B, int N, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
+                       double b1, double b2, double eps, double wd, double gscale, hipStream_t s);
+
+}  // namespace psvae

@@ -1,0 +1,158 @@
+"""TrainEngine: the native training-step driver for the hot path.
+
+One process per GPU.  Parameters, gradients and Adam state live in flat fp32 buffers (the 18 tensors
+in the reference's creation order, model.py:14-36, each 256-B aligned), so that
+  * the HIP kernels write gradients straight into the all-reduce payload,
+  * data-parallel averaging (the reference's DDPStrategy, training.py:78) is TWO RCCL all-reduces
+    per step: the decoder bucket is issued as soon as backward phase 1 has been enqueued and runs
+    on RCCL's stream underneath the encoder backward (phase 2); the encoder bucket carries the three
+    loss scalars too (replaces Lightning's per-key `sync_dist` all-reduces, lightning.py:127-129),
+  * Adam (lightning.py:205) is one fused kernel over the flat buffer with the 1/world scale folded in.
+On one GPU the whole step (forward + ELBO + backward [+ Adam]) can be captured into a HIP graph.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _ffi, ops
+from .model import VAEModel
+
+ALIGN = 64  # floats (256 B)
+
+
+def _pad(n: int) -> int:
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class FlatLayout:
+    """[encoder_mu x6 | encoder_sigma x6 | loss3 | decoder x6] -- decoder last = first bucket to reduce."""
+
+    def __init__(self, shapes: List[torch.Size]):
+        assert len(shapes) == _ffi.NPARAM
+        self.shapes = list(shapes)
+        self.offsets = []
+        o = 0
+        for i, s in enumerate(shapes):
+            if i == 12:
+                self.loss_offset = o
+                o += ALIGN
+                self.enc_end = o
+            self.offsets.append(o)
+            o += _pad(s.numel())
+        self.total = o
+
+    def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        return [flat[o:o + s.numel()].view(s) for o, s in zip(self.offsets, self.shapes)]
+
+
+class TrainEngine:
+    def __init__(self, input_dim: int, latent_dim: int, batch: int, device="cuda:0", seed: int = 0,
+                 beta: float = 1.0, normalize_decoder: bool = False, use_cos_loss: bool = False,
+                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 process_group=None, state_dict=None):
+        self.D, self.Z, self.B = input_dim, latent_dim, batch
+        self.device = torch.device(device)
+        self.beta = float(beta)
+        self.flags = (_ffi.NORMALIZE_DECODER if normalize_decoder else 0) | (_ffi.COS_LOSS if use_cos_loss else 0)
+        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+
+        # default nn.Linear init in the reference's creation order under `seed` (CPU generator), so
+        # every rank starts from identical parameters without a broadcast (Coll-4 of SURVEY.md 2.2)
+        torch.manual_seed(seed)
+        cpu_model = VAEModel(input_dim, latent_dim, normalize_decoder)
+        if state_dict is not None:
+            cpu_model.load_state_dict(state_dict)
+        src = [p.detach() for p in cpu_model.ordered_params()]
+        self.keys = [k for k, _ in cpu_model.named_parameters()]
+        self.layout = FlatLayout([p.shape for p in src])
+        n = self.layout.total
+        self.flat_params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.params = self.layout.views(self.flat_params)
+        self.grads = self.layout.views(self.flat_grads)
+        for dst, s in zip(self.params, src):
+            dst.copy_(s)
+        self.loss3 = self.flat_grads[self.layout.loss_offset:self.layout.loss_offset + 3]
+        self.enc_bucket = self.flat_grads[:self.layout.enc_end]
+        self.dec_bucket = self.flat_grads[self.layout.enc_end:]
+        self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
+        self.outs = self.ws.new_outputs()
+        self.step_count = 0
+        # device-resident Philox state {seed, offset}: advanced by the forward itself (graph-safe)
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+        self._graph = None
+        self.static_x = None
+
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self):
+        return {k: p.detach().clone() for k, p in zip(self.keys, self.params)}
+
+    def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
+        Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
+        xh, mu, lv = ops.vae_forward(self.ws, x, self.params, eps, 0, 0, self.flags, outs=self.outs,
+                                     rng_state=self.rng_state)
+        ops.elbo(self.ws, x, xh, mu, lv, self.beta, self.flags, self.loss3)
+        if self.world == 1:
+            ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
+                             flags=self.flags)
+            return
+        import torch.distributed as dist
+        ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
+                         flags=self.flags, phases=_ffi.PHASE_DECODER)
+        w1 = self._allreduce(self.dec_bucket)          # runs under the encoder backward
+        ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
+                         flags=self.flags, phases=_ffi.PHASE_ENCODER)
+        w2 = self._allreduce(self.enc_bucket)          # + the 3 loss scalars
+        w1.wait()
+        w2.wait()
+        if self._sum_only:
+            self.flat_grads.mul_(1.0 / self.world)
+
+    def _allreduce(self, t: torch.Tensor):
+        import torch.distributed as dist
+        backend = dist.get_backend(self.pg)
+        self._sum_only = backend != "nccl"
+        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+        return dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """fused Adam over the flat buffers (lightning.py:205)."""
+        self.step_count += 1
+        ops.adam_step(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count,
+                      self.lr if lr is None else lr, self.betas, self.adam_eps, self.weight_decay)
+        # the loss slot inside flat_grads is "trained" too but belongs to no parameter: harmless
+
+    # ------------------------------------------------------------------------------------------
+    def capture(self, x: torch.Tensor):
+        """Capture forward + ELBO + backward into one HIP graph (single GPU; launch-bound otherwise:
+        ~20 kernels of a few microseconds each).  The captured step reads its batch from a static
+        buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which
+        the graph itself advances, so every replay draws fresh noise."""
+        if self.world != 1:
+            raise _ffi.PsvaeError("graph capture is for the single-GPU path; RCCL collectives stay eager")
+        self.static_x = x.detach().clone()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture (hipFuncSetAttribute, lazy module load)
+                self.forward_backward(self.static_x)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(self.static_x)
+        self._graph = g
+        return g
+
+    def replay(self):
+        self._graph.replay()

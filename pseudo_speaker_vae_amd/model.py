@@ -1,0 +1,252 @@
+"""VAEModel: the reference's nn.Module API (/root/reference/ps_vae/model.py:7-69) over the HIP hot path.
+
+Same constructor, same `forward(x) -> (x_hat, mu, log_sigma)` / `decode(z)`, same 18 state_dict keys
+and shapes, same default-init RNG consumption (the nn.Sequential containers are kept as parameter
+holders only; their forward is never used).  All arithmetic runs in libpsvae_hip.so through two
+torch.autograd.Functions; inputs must live on the GPU -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _ffi, ops
+
+HIDDEN = _ffi.HIDDEN
+
+
+class _Buffers:
+    """Per-(shape, device) cache of scratch + ctypes structs; activations are allocated per call
+    (one flat tensor) because several forwards may be alive before their backward."""
+
+    def __init__(self):
+        self._scratch: Dict[tuple, torch.Tensor] = {}
+
+    def scratch(self, B, D, Z, device) -> torch.Tensor:
+        key = (B, D, Z, str(device))
+        t = self._scratch.get(key)
+        if t is None:
+            if len(self._scratch) > 8:
+                self._scratch.clear()
+            t = torch.empty(_ffi.scratch_bytes(B, D, Z), dtype=torch.uint8, device=device)
+            self._scratch[key] = t
+        return t
+
+
+_ACT_ORDER = ("h1m", "h2m", "h1s", "h2s", "d1", "d2", "eps", "z")
+
+
+def _alloc_acts(B: int, D: int, Z: int, device, normalize: bool):
+    """one allocation: 6 x [B,512] + 2 x [B,Z] (+ [B]) activations and the 3 outputs."""
+    sizes = [B * HIDDEN] * 6 + [B * Z] * 2 + [B * D, B * Z, B * Z] + ([B] if normalize else [])
+    pad = [(s + 63) // 64 * 64 for s in sizes]  # 256-B aligned carve
+    flat = torch.empty(sum(pad), dtype=torch.float32, device=device)
+    views, o = [], 0
+    for s, p in zip(sizes, pad):
+        views.append(flat[o:o + s])
+        o += p
+    acts = {k: v.view(B, -1) for k, v in zip(_ACT_ORDER, views[:8])}
+    xh, mu, lv = views[8].view(B, D), views[9].view(B, Z), views[10].view(B, Z)
+    if normalize:
+        acts["ynorm"] = views[11]
+    return acts, xh, mu, lv
+
+
+def _alloc_like_flat(tensors):
+    """gradients for `tensors` carved out of ONE flat buffer (a single all-reduce payload)."""
+    sizes = [t.numel() for t in tensors]
+    pad = [(s + 63) // 64 * 64 for s in sizes]
+    flat = torch.empty(sum(pad), dtype=torch.float32, device=tensors[0].device)
+    out, o = [], 0
+    for t, s, p in zip(tensors, sizes, pad):
+        out.append(flat[o:o + s].view_as(t))
+        o += p
+    return out
+
+
+class _Ctx:
+    """what backward needs, shared by both Functions"""
+    __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors")
+
+
+def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_tensors=None):
+    if not x.is_cuda:
+        raise _ffi.PsvaeError("VAEModel runs on the GPU only (HIP kernels); move the module and its input to cuda")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise _ffi.PsvaeError(f"expected float32 input, got {x.dtype}")
+    B, D = x.shape
+    Z = params[4].shape[0]
+    if params[0].shape[1] != D:
+        raise _ffi.PsvaeError(f"input has {D} features, the model expects {params[0].shape[1]}")
+    normalize = bool(flags & _ffi.NORMALIZE_DECODER)
+    c = _Ctx()
+    c.B, c.D, c.Z, c.flags = B, D, Z, flags
+    c.acts, xh, mu, lv = _alloc_acts(B, D, Z, x.device, normalize)
+    c.acts_c = _ffi.make_acts(c.acts)
+    c.scratch = buffers.scratch(B, D, Z, x.device)
+    c.dims = _ffi.Dims(B, D, Z)
+    c.cond_tensors = cond_tensors
+    ws = _WsView(c)
+    cond = _make_cond(cond_tensors, None)
+    ops.vae_forward(ws, x, params, eps, seed, offset, flags, cond=cond, outs=(xh, mu, lv))
+    return c, x, xh, mu, lv
+
+
+def _make_cond(cond_tensors, gtabs):
+    if cond_tensors is None:
+        return None
+    tabs, gender, age = cond_tensors
+    return _ffi.make_cond(tabs, gtabs, gender, age)
+
+
+class _WsView:
+    """adapts a _Ctx to the ops.Workspace duck type"""
+
+    def __init__(self, c: _Ctx):
+        self.B, self.D, self.Z = c.B, c.D, c.Z
+        self.dims, self.acts, self.acts_c, self.scratch = c.dims, c.acts, c.acts_c, c.scratch
+
+
+class VAEForwardFunction(torch.autograd.Function):
+    """(x_hat, mu, logvar) = VAE(x); differentiable w.r.t. the 18 parameters (and x if it asks)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, meta, *params):
+        seed, offset, flags, buffers = meta
+        params = [p.detach() for p in params]
+        c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, params, buffers)
+        ctx.c, ctx.params, ctx.x = c, params, x
+        ctx.save_for_backward(xh, mu, lv)
+        ctx.set_materialize_grads(False)
+        return xh, mu, lv
+
+    @staticmethod
+    def backward(ctx, g_xh, g_mu, g_lv):
+        xh, mu, lv = ctx.saved_tensors
+        c = ctx.c
+        grads = _alloc_like_flat(ctx.params)
+        g_x = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
+        cg = lambda g: None if g is None else g.contiguous()
+        if g_xh is None and not (c.flags & _ffi.NORMALIZE_DECODER):
+            g_xh = torch.zeros_like(xh)  # decoder still needs a defined upstream gradient
+        ops.vae_backward(_WsView(c), ctx.x, ctx.params, xh, mu, lv, grads, g_xhat=cg(g_xh), g_mu=cg(g_mu),
+                         g_logvar=cg(g_lv), elbo_grad=False, g_x=g_x, flags=c.flags)
+        return (g_x, None, None, *grads)
+
+
+class ELBOStepFunction(torch.autograd.Function):
+    """total, recon, kl = ELBO(VAE(x), x): forward + loss in one Function; backward runs the fused
+    gradient path with the upstream d/d(total) read on the device (no host sync).  Returns
+    (total, recon, kl, x_hat, mu, logvar); only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, eps, meta, *params):
+        seed, offset, flags, buffers, beta, cond_tensors = meta
+        params = [p.detach() for p in params]
+        ncond = 3 if cond_tensors is not None else 0
+        vae_params = params[:_ffi.NPARAM]
+        if ncond:
+            cond_tensors = (params[_ffi.NPARAM:], cond_tensors[1], cond_tensors[2])
+        c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers, cond_tensors)
+        loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        ops.elbo(_WsView(c), x, xh, mu, lv, beta, flags, loss3)
+        ctx.c, ctx.params, ctx.x, ctx.beta = c, params, x, beta
+        ctx.save_for_backward(xh, mu, lv)
+        total, recon, kl = loss3[0], loss3[1], loss3[2]
+        ctx.mark_non_differentiable(recon, kl, xh, mu, lv)
+        return total, recon, kl, xh, mu, lv
+
+    @staticmethod
+    def backward(ctx, g_total, *_):
+        xh, mu, lv = ctx.saved_tensors
+        c = ctx.c
+        grads = _alloc_like_flat(ctx.params)
+        cond = _make_cond(c.cond_tensors, grads[_ffi.NPARAM:]) if c.cond_tensors is not None else None
+        ops.vae_backward(_WsView(c), ctx.x, ctx.params[:_ffi.NPARAM], xh, mu, lv, grads[:_ffi.NPARAM],
+                         elbo_grad=True, beta=ctx.beta, grad_loss=g_total.contiguous().float(), flags=c.flags,
+                         cond=cond)
+        return (None, None, None, *grads)
+
+
+class DecodeFunction(torch.autograd.Function):
+    """x_hat = decoder(z); differentiable w.r.t. z and the decoder parameters through the same kernels."""
+
+    @staticmethod
+    def forward(ctx, z, flags, *dec):
+        if not z.is_cuda:
+            raise _ffi.PsvaeError("VAEModel.decode runs on the GPU only (HIP kernels)")
+        dec = [p.detach() for p in dec]
+        D = dec[4].shape[0]
+        ctx.set_materialize_grads(False)
+        if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:]):
+            raise _ffi.PsvaeError("decode() under autograd is not supported yet: wrap the call in torch.no_grad()")
+        return ops.decode(z.detach().float(), dec, D, flags)
+
+    @staticmethod
+    def backward(ctx, g):  # pragma: no cover
+        raise _ffi.PsvaeError("decode() backward is not implemented")
+
+
+class VAEModel(nn.Module):
+    """Drop-in for ps_vae.model.VAEModel (model.py:7-69)."""
+
+    def __init__(self, input_dim: int = 512, latent_dim: int = 64, normalize_decoder: bool = False):
+        super().__init__()
+        self.normalize_decoder = normalize_decoder
+        # parameter containers only (identical key names / shapes / init order: model.py:14-36)
+        def mlp(i, o):
+            return nn.Sequential(nn.Linear(i, HIDDEN), nn.ReLU(), nn.Linear(HIDDEN, HIDDEN), nn.ReLU(),
+                                 nn.Linear(HIDDEN, o))
+        self.encoder_mu = mlp(input_dim, latent_dim)
+        self.encoder_sigma = mlp(input_dim, latent_dim)
+        self.decoder = mlp(latent_dim, input_dim)
+        self.input_dim, self.latent_dim = input_dim, latent_dim
+        self._scratch_cache = _Buffers()
+        self._philox_offset = 0  # Philox blocks consumed so far (advances every forward)
+
+    # ---- helpers -------------------------------------------------------------------------
+    def ordered_params(self) -> List[torch.Tensor]:
+        """the 18 tensors in C-ABI order (== creation order == state_dict order)"""
+        out = []
+        for blk in (self.encoder_mu, self.encoder_sigma, self.decoder):
+            for i in (0, 2, 4):
+                out += [blk[i].weight, blk[i].bias]
+        return out
+
+    @property
+    def flags(self) -> int:
+        return _ffi.NORMALIZE_DECODER if self.normalize_decoder else 0
+
+    def _next_rng(self, n_elems: int) -> Tuple[int, int]:
+        """(seed, offset) of this call's epsilon stream: seed follows torch.manual_seed, the offset
+        advances by the Philox blocks the call consumes, so successive forwards never reuse noise."""
+        seed = torch.initial_seed() & ((1 << 64) - 1)
+        off = self._philox_offset
+        self._philox_offset += (n_elems + 3) // 4
+        return seed, off
+
+    # ---- reference API -------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """model.py:38-63.  Returns (x_hat, mu, log_sigma) where log_sigma is the log-variance.
+        `eps` (optional, extension) injects the N(0,1) draw instead of the Philox stream."""
+        seed, off = self._next_rng(x.shape[0] * self.latent_dim)
+        meta = (seed, off, self.flags, self._scratch_cache)
+        return VAEForwardFunction.apply(x, eps, meta, *self.ordered_params())
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """model.py:65-69."""
+        return DecodeFunction.apply(z, self.flags, *self.ordered_params()[12:])
+
+    def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
+                  eps: Optional[torch.Tensor] = None):
+        """fused forward + ELBO (lightning.py:110-124): returns (total, recon, kl, x_hat, mu, logvar)."""
+        seed, off = self._next_rng(x.shape[0] * self.latent_dim)
+        flags = self.flags | (_ffi.COS_LOSS if use_cos_loss else 0)
+        meta = (seed, off, flags, self._scratch_cache, float(beta), None)
+        return ELBOStepFunction.apply(x, eps, meta, *self.ordered_params())
+
+
+PsVAE = VAEModel  # the name BASELINE.json uses

@@ -1,0 +1,141 @@
+"""Functional layer over the C-ABI: torch tensors in / out, all compute in libpsvae_hip.so.
+
+PyTorch is used for device memory and streams only.  Everything here requires CUDA(HIP) tensors;
+there is deliberately no CPU path (see _ffi.ptr).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _ffi
+from ._ffi import HIDDEN, NPARAM
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_ACCUM = 0, 1, 2, 3, 4
+
+ACT_SHAPES = {
+    "h1m": lambda B, D, Z: (B, HIDDEN), "h2m": lambda B, D, Z: (B, HIDDEN),
+    "h1s": lambda B, D, Z: (B, HIDDEN), "h2s": lambda B, D, Z: (B, HIDDEN),
+    "eps": lambda B, D, Z: (B, Z), "z": lambda B, D, Z: (B, Z),
+    "d1": lambda B, D, Z: (B, HIDDEN), "d2": lambda B, D, Z: (B, HIDDEN),
+    "ynorm": lambda B, D, Z: (B,),
+}
+
+
+def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _ffi.PsvaeError(f"{what} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def philox_normal(n: int, seed: int, offset: int, device) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    _ffi.check(_ffi.lib().psvae_philox_normal_f32(_ffi.ptr(out), n, seed, offset, _ffi.stream_ptr()), "philox_normal")
+    return out
+
+
+def gemm(kind: int, A: torch.Tensor, B: torch.Tensor, epi: int = EPI_NONE, aux: Optional[torch.Tensor] = None,
+         want_colsum: bool = False, tile: int = 0, out: Optional[torch.Tensor] = None):
+    """Test/bench hook: one grouped-kernel GEMM.  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
+    A, B = _f32(A, "A"), _f32(B, "B")
+    if kind == GEMM_NT:
+        (M, K), (N, K2) = A.shape, B.shape
+    elif kind == GEMM_NN:
+        (M, K), (K2, N) = A.shape, B.shape
+    else:
+        (K, M), (K2, N) = A.shape, B.shape
+    assert K == K2, "contraction mismatch"
+    Cm = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    cs = torch.empty(M, dtype=torch.float32, device=A.device) if want_colsum else None
+    _ffi.check(_ffi.lib().psvae_gemm_f32(kind, M, N, K, _ffi.ptr(A), A.stride(0), _ffi.ptr(B), B.stride(0),
+                                         _ffi.ptr(Cm), Cm.stride(0), _ffi.ptr(aux), _ffi.ptr(cs), epi, tile,
+                                         _ffi.stream_ptr()), "gemm")
+    return (Cm, cs) if want_colsum else Cm
+
+
+class Workspace:
+    """Caller-owned buffers of one batch shape: saved activations, outputs, scratch, gradients."""
+
+    def __init__(self, B: int, D: int, Z: int, device, normalize: bool = False):
+        self.B, self.D, self.Z = B, D, Z
+        self.device = torch.device(device)
+        self.dims = _ffi.Dims(B, D, Z)
+        self.acts: Dict[str, torch.Tensor] = {
+            k: torch.empty(f(B, D, Z), dtype=torch.float32, device=device)
+            for k, f in ACT_SHAPES.items() if (k != "ynorm" or normalize)}
+        self.acts_c = _ffi.make_acts(self.acts)
+        nbytes = _ffi.scratch_bytes(B, D, Z)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.loss3 = torch.zeros(3, dtype=torch.float32, device=device)
+
+    def new_outputs(self):
+        B, D, Z = self.B, self.D, self.Z
+        return (torch.empty(B, D, dtype=torch.float32, device=self.device),
+                torch.empty(B, Z, dtype=torch.float32, device=self.device),
+                torch.empty(B, Z, dtype=torch.float32, device=self.device))
+
+
+def vae_forward(ws: Workspace, x: torch.Tensor, params: Sequence[torch.Tensor], eps: Optional[torch.Tensor] = None,
+                seed: int = 0, offset: int = 0, flags: int = 0, cond=None,
+                outs: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+                rng_state: Optional[torch.Tensor] = None):
+    """VAEModel.forward on the GPU: returns (x_hat, mu, logvar); activations land in ws.acts."""
+    x = _f32(x, "x")
+    assert x.shape == (ws.B, ws.D), (x.shape, ws.B, ws.D)
+    xh, mu, lv = outs if outs is not None else ws.new_outputs()
+    P = _ffi.make_params(params)
+    _ffi.check(_ffi.lib().psvae_forward_f32(
+        C.byref(ws.dims), _ffi.ptr(x), C.byref(P), C.byref(cond) if cond is not None else None,
+        _ffi.ptr(_f32(eps, "eps")) if eps is not None else None, seed, offset, _ffi.ptr(rng_state),
+        C.byref(ws.acts_c),
+        _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv), _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()), "forward")
+    return xh, mu, lv
+
+
+def elbo(ws: Workspace, x, xh, mu, lv, beta: float, flags: int = 0, loss3: Optional[torch.Tensor] = None):
+    loss3 = ws.loss3 if loss3 is None else loss3
+    _ffi.check(_ffi.lib().psvae_elbo_f32(C.byref(ws.dims), _ffi.ptr(x), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv),
+                                         beta, _ffi.ptr(loss3), _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()), "elbo")
+    return loss3
+
+
+def vae_backward(ws: Workspace, x, params: Sequence[torch.Tensor], xh, mu, lv, grads: Sequence[torch.Tensor],
+                 g_xhat=None, g_mu=None, g_logvar=None, elbo_grad: bool = False, beta: float = 1.0,
+                 grad_loss: Optional[torch.Tensor] = None, g_x: Optional[torch.Tensor] = None, flags: int = 0,
+                 phases: int = _ffi.PHASE_ALL, cond=None):
+    P = _ffi.make_params(params)
+    G = _ffi.make_grads(grads)
+    _ffi.check(_ffi.lib().psvae_backward_f32(
+        C.byref(ws.dims), _ffi.ptr(x), C.byref(P), C.byref(cond) if cond is not None else None,
+        C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv),
+        _ffi.ptr(g_xhat), _ffi.ptr(g_mu), _ffi.ptr(g_logvar), int(elbo_grad), beta, _ffi.ptr(grad_loss),
+        C.byref(G), _ffi.ptr(g_x), _ffi.ptr(ws.scratch), flags, phases, _ffi.stream_ptr()), "backward")
+    return grads
+
+
+def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
+           cond_tab=None, gender=None, age=None, out: Optional[torch.Tensor] = None,
+           scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """VAEModel.decode on the GPU (decoder tensors = params[12:18])."""
+    z = _f32(z, "z")
+    N, Z = z.shape
+    xh = out if out is not None else torch.empty(N, D, dtype=torch.float32, device=z.device)
+    nbytes = int(_ffi.lib().psvae_decode_scratch_bytes(N))
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+    arr = (C.c_void_p * 6)(*[_ffi.ptr(_f32(t, "decoder param")) for t in dec_params])
+    _ffi.check(_ffi.lib().psvae_decode_f32(N, D, Z, _ffi.ptr(z), arr, _ffi.ptr(cond_tab), _ffi.ptr(gender),
+                                           _ffi.ptr(age), _ffi.ptr(xh), _ffi.ptr(scratch), flags,
+                                           _ffi.stream_ptr()), "decode")
+    return xh
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+              weight_decay: float = 0.0, grad_scale: float = 1.0):
+    n = param.numel()
+    _ffi.check(_ffi.lib().psvae_adam_step_f32(_ffi.ptr(param), _ffi.ptr(grad), _ffi.ptr(exp_avg), _ffi.ptr(exp_avg_sq),
+                                              n, step, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
+                                              _ffi.stream_ptr()), "adam_step")
