@@ -38,7 +38,9 @@ def flop_per_embedding(D: int, Z: int) -> int:
 def cpu_baseline(D, Z, B, steps=40, warmup=3):
     """oracle fwd+ELBO+bwd on the host cores (checker code used as the timed CPU port)."""
     from oracle import psvae_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one job a 16-core share of a 256-thread host: more threads only thrash
+    ncores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(ncores)
     p = O.init_params(D, Z, 0)
     torch.manual_seed(0)
     x = torch.randn(B, D)

@@ -86,6 +86,8 @@ typedef struct psvae_acts {
 } psvae_acts;
 
 int psvae_version(void);
+/* tuning hook: force the GEMM config (1..9, see gemm_f32.hip) of every later launch; 0 = automatic */
+int psvae_debug_force_tile(int tile);
 const char* psvae_strerror(int code);
 
 /* bytes of scratch the calls below need for a batch of B rows (any call; take the max over calls) */
@@ -136,7 +138,8 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
  *   kind 0 (NT): C[M,N] = A[M,K] B[N,K]^T     (forward Linear, model.py:15)
  *   kind 1 (NN): C[M,N] = A[M,K] B[K,N]       (dgrad)
  *   kind 2 (TN): C[M,N] = A[K,M]^T B[K,N]     (wgrad; colsum != NULL also writes sum_k A[k,:])
- *   epi 0 none, 1 +bias[N], 2 relu(+bias), 3 * (mask[M,N] > 0).  tile: 0 = auto, else (TM<<4)|TN. */
+ *   epi 0 none, 1 +bias[N], 2 relu(+bias), 3 * (mask[M,N] > 0), 4 C += .  tile: 0 = auto, else a
+ *   config id 1..9 (wave tile / k-split table in csrc/gemm_f32.hip). */
 int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask,
                    float* colsum, int epi, int tile, void* stream);

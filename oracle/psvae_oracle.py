@@ -147,35 +147,44 @@ def elbo_grads(x_hat, x, mu, lv, beta: float = 1.0, use_cos_loss: bool = False, 
 # --------------------------------------------------------------------------------------
 # backward (autograd of model.py:54-61; closed forms of SURVEY.md Appendix A)
 # --------------------------------------------------------------------------------------
-def _mlp3_backward(g_y, x_in, h1, h2, p, blk, grads, need_dx: bool):
+def _mlp3_backward(g_y, x_in, h1, h2, p, blk, grads, need_dx: bool, m1=None, m2=None):
+    """m1/m2: optional ReLU masks overriding (h1 > 0)/(h2 > 0) -- see `backward(masks=...)`."""
     W2, W3 = p[f"{blk}.2.weight"], p[f"{blk}.4.weight"]
     grads[f"{blk}.4.weight"] = g_y.t() @ h2
     grads[f"{blk}.4.bias"] = g_y.sum(0)
-    g_h2 = (g_y @ W3) * (h2 > 0)
+    g_h2 = (g_y @ W3) * ((h2 > 0) if m2 is None else m2)
     grads[f"{blk}.2.weight"] = g_h2.t() @ h1
     grads[f"{blk}.2.bias"] = g_h2.sum(0)
-    g_h1 = (g_h2 @ W2) * (h1 > 0)
+    g_h1 = (g_h2 @ W2) * ((h1 > 0) if m1 is None else m1)
     grads[f"{blk}.0.weight"] = g_h1.t() @ x_in
     grads[f"{blk}.0.bias"] = g_h1.sum(0)
     return (g_h1 @ p[f"{blk}.0.weight"]) if need_dx else None
 
 
 def backward(p, x, acts, g_xhat, g_mu_direct=None, g_lv_direct=None,
-             normalize_decoder: bool = False, need_dx: bool = False):
-    """Gradients of the 18 parameters given d/d(x_hat), plus direct d/d(mu), d/d(logvar) terms."""
+             normalize_decoder: bool = False, need_dx: bool = False, masks=None):
+    """Gradients of the 18 parameters given d/d(x_hat), plus direct d/d(mu), d/d(logvar) terms.
+
+    `masks` (optional dict h1m,h2m,h1s,h2s,d1,d2 -> bool tensors) replaces the ReLU derivative
+    masks (h > 0).  The ReLU derivative is discontinuous at 0: two fp32 implementations whose
+    pre-activations differ in the last bit can legitimately disagree on the mask of an element that
+    sits within rounding of 0, which moves a whole row of dW by O(1/sqrt(B)).  Parity tests therefore
+    compare gradients at EQUAL masks (taken from the implementation under test) and separately
+    check that the masks differ from the oracle's only where |activation| is within rounding of 0."""
     grads: Dict[str, torch.Tensor] = {}
+    mk = (lambda k: None) if masks is None else (lambda k: masks[k])
     g_y = g_xhat
     if normalize_decoder:  # backward of y / max(||y||, eps)
         xh, n = acts["x_hat"], acts["ynorm"]
         clamped = n <= 1e-12
         g_y = torch.where(clamped, g_xhat / n, (g_xhat - xh * (g_xhat * xh).sum(1, keepdim=True)) / n)
-    g_z = _mlp3_backward(g_y, acts["z"], acts["d1"], acts["d2"], p, "decoder", grads, True)
+    g_z = _mlp3_backward(g_y, acts["z"], acts["d1"], acts["d2"], p, "decoder", grads, True, mk("d1"), mk("d2"))
     g_mu = g_z if g_mu_direct is None else g_z + g_mu_direct
     g_lv = g_z * acts["eps"] * 0.5 * acts["sigma"]
     if g_lv_direct is not None:
         g_lv = g_lv + g_lv_direct
-    gx_m = _mlp3_backward(g_mu, x, acts["h1m"], acts["h2m"], p, "encoder_mu", grads, need_dx)
-    gx_s = _mlp3_backward(g_lv, x, acts["h1s"], acts["h2s"], p, "encoder_sigma", grads, need_dx)
+    gx_m = _mlp3_backward(g_mu, x, acts["h1m"], acts["h2m"], p, "encoder_mu", grads, need_dx, mk("h1m"), mk("h2m"))
+    gx_s = _mlp3_backward(g_lv, x, acts["h1s"], acts["h2s"], p, "encoder_sigma", grads, need_dx, mk("h1s"), mk("h2s"))
     extra = dict(g_z=g_z, g_mu=g_mu, g_lv=g_lv)
     if need_dx:
         extra["g_x"] = gx_m + gx_s
@@ -183,15 +192,13 @@ def backward(p, x, acts, g_xhat, g_mu_direct=None, g_lv_direct=None,
 
 
 def train_step(p, x, eps, beta: float = 1.0, normalize_decoder: bool = False,
-               use_cos_loss: bool = False, go: float = 1.0):
+               use_cos_loss: bool = False, go: float = 1.0, masks=None):
     """forward + ELBO + backward: what one Lightning training_step + loss.backward() computes
     (lightning.py:67-131 without classifier / consistency branches)."""
     acts = forward(p, x, eps, normalize_decoder)
     recon, kl, total = elbo(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, use_cos_loss)
     g_xh, g_mu_d, g_lv_d = elbo_grads(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, use_cos_loss, go)
-    if use_cos_loss:
-        pass  # the cos loss has no direct x dependence through x_hat other than g_xh
-    grads, extra = backward(p, x, acts, g_xh, g_mu_d, g_lv_d, normalize_decoder)
+    grads, extra = backward(p, x, acts, g_xh, g_mu_d, g_lv_d, normalize_decoder, masks=masks)
     return dict(recon=recon, kl=kl, total=total), grads, acts, extra
 
 

@@ -24,7 +24,7 @@ ABI_VERSION = 1
 
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
-    "psvae_version", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
+    "psvae_version", "psvae_debug_force_tile", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32",
 )

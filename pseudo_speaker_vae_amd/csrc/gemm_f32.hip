@@ -2,121 +2,92 @@
 // (forward NT, dgrad NN, wgrad TN; reference: nn.Linear at /root/reference/ps_vae/model.py:14-36 and
 // its autograd).  Exact fp32: v_mfma_f32_16x16x4_f32, which is a k-ordered fmaf chain.
 //
-// Design (see DESIGN.md "GEMM kernel"):
-//   * one launch = a GROUP of independent problems (both encoders; a layer's wgrad + dgrad), so a
-//     1024-row batch still fills 256 CUs; each 256-thread workgroup (4 waves, 2x2) owns one
-//     (32*TM) x (32*TN) output tile, each wave a (16*TM) x (16*TN) sub-tile of 16x16 MFMA blocks;
-//   * operands are staged global -> registers -> LDS in their NATIVE orientation, 16 B per lane,
-//     full 128-B lines per row, double-buffered (loads of tile k+1 fly under the MFMAs of tile k):
-//       "KC" operand (k contiguous in memory: activations / weights in NT, dY in NN): LDS tile
-//            [rows][40] floats, fragment = one ds_read_b128 per 16-k chunk (4 k's per lane, used
-//            by 4 consecutive MFMAs; the k permutation is applied identically to A and B);
-//       "KM" operand (k-major: W in NN, both operands of the batch-contracting wgrad): LDS tile
-//            [32][rows(+pad)], fragment = one ds_read_b{32,64,128} per k giving T adjacent rows
-//            = the T MFMA blocks of the wave (row slot c of block e  <->  row T*c + e);
-//     strides 40 / R+{4,8,0} make every fragment read bank-conflict-free (tools/lds_bank_check.py);
-//   * epilogues fused: +bias, ReLU, ReLU-mask (dgrad), bias-gradient column sums (wgrad, from the
-//     A fragments already in registers: VALU adds beside the MFMAs, no extra pass over dY).
+// Design -- "register-direct", chosen by measurement (tools/microbench/rd_gemm.hip):
+// the VAE's GEMMs are small (<= 1 GFLOP, K <= 1024) and fp32 MFMA is slow enough (64 FLOP/clk/SIMD)
+// that L1/L2 can feed the matrix pipe directly, while LDS staging (ds_write + barrier per k tile)
+// cost as much as the MFMAs themselves at the small tiles needed to fill 256 CUs.  So:
+//   * no LDS and no barrier in the k loop: every wave loads its own MFMA fragments global -> VGPR,
+//     16 B per lane, D chunks of 16 k in flight (the 512-entry register file is the prefetch buffer);
+//       "KC" operand (k contiguous: activations, W[out,in] in NT, dY in NN): lane (r,q) loads k =
+//            16c+4q..+3 of row 16b+r; the 4 values feed 4 consecutive MFMAs (the same k permutation
+//            is applied to both operands, so the sum is unchanged);
+//       "KM" operand (k-major: W in NN, both operands of the batch-contracting wgrad): lane (r,q)
+//            loads T adjacent rows of k = 16c+4q+t -- whole 64..256-B row segments per k;
+//   * one workgroup = 4 waves = WM x WN spatial waves x KS k-slices (split-K INSIDE the workgroup):
+//     a 1024-row batch still gives >= 1 wave per SIMD, and the long-K wgrad (K = batch) is cut in 4;
+//     partial tiles meet in LDS once, after the loop, where the k-slices are summed in fixed order
+//     (bitwise reproducible) and the tile leaves as whole rows, 16 B per lane, with the fused
+//     epilogue (+bias, ReLU, ReLU-mask, accumulate) applied on the way out;
+//   * one launch = a GROUP of independent problems (both encoders; a layer's wgrad + dgrad);
+//   * bias gradients (column sums of dY) come from the A fragments already in registers.
 #include "psvae_common.h"
 
 namespace psvae {
 
-constexpr int BK = 32;    // k per LDS tile
-constexpr int S_KC = 40;  // KC tile row stride in floats (conflict-free ds_read_b128 along k)
 constexpr int NTHR = 256;
-
-__host__ __device__ constexpr int km_stride(int R, int T) { return T == 4 ? R : (T == 2 ? R + 8 : R + 4); }
-__host__ __device__ constexpr int tile_floats(bool km, int R, int T) { return km ? BK * km_stride(R, T) : R * S_KC; }
-__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
-// LDS floats for one (A,B) pair, worst case over the three kinds
-__host__ __device__ constexpr int pair_floats(int TM, int TN) {
-    return cmax(tile_floats(false, 32 * TM, TM), tile_floats(true, 32 * TM, TM)) +
-           cmax(tile_floats(false, 32 * TN, TN), tile_floats(true, 32 * TN, TN));
-}
 
 template <int T> struct VecT;
 template <> struct VecT<1> { typedef float type; };
 template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<4> { typedef f32x4 type; };
-
 template <int T> __device__ __forceinline__ float vget(const typename VecT<T>::type& v, int i);
 template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
 template <> __device__ __forceinline__ float vget<2>(const f32x2& v, int i) { return v[i]; }
 template <> __device__ __forceinline__ float vget<4>(const f32x4& v, int i) { return v[i]; }
 
-// guarded 4-float global load: (row_ok, c..c+3 < cmaxv) else zero fill
-__device__ __forceinline__ f32x4 gload4(const float* __restrict__ p, int c, int cmaxv, bool row_ok, bool vec_ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-        if (vec_ok && c + 3 < cmaxv) {
-            v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < cmaxv) v[e] = p[e];
-        }
-    }
-    return v;
+// Pointers arrive inside a by-value struct, for which hipcc falls back to FLAT accesses (flat loads
+// count on vmcnt AND lgkmcnt and return out of order, so every use drains both counters and the
+// prefetch pipeline collapses).  All global traffic therefore goes through explicit address-space-1
+// accessors.
+#define PSVAE_GLOBAL __attribute__((address_space(1)))
+template <typename V>
+__device__ __forceinline__ V ldg(const float* p) {
+    return *reinterpret_cast<const PSVAE_GLOBAL V*>(reinterpret_cast<uintptr_t>(p));
+}
+template <typename V>
+__device__ __forceinline__ void stg(float* p, const V& v) {
+    *reinterpret_cast<PSVAE_GLOBAL V*>(reinterpret_cast<uintptr_t>(p)) = v;
 }
 
-// ---- staging: one operand tile, global -> registers ------------------------------------------
-// KC: tile rows r0..r0+R-1 (bounded by rmax), k0..k0+31 (bounded by K); memory [row][k], ld
-// KM: tile k rows k0..k0+31 (bounded by K), cols r0..r0+R-1 (bounded by rmax); memory [k][row], ld
-template <int R, bool KM>
-__device__ __forceinline__ void stage_load(f32x4 (&reg)[R / 32], const float* __restrict__ base, int ld, int r0,
-                                           int rmax, int k0, int K, bool vec_ok, int tid) {
-#pragma unroll
-    for (int j = 0; j < R / 32; ++j) {
-        const int i = tid + NTHR * j;
-        if (!KM) {
-            const int row = i >> 3, kq = i & 7;
-            const int gr = r0 + row, gk = k0 + 4 * kq;
-            reg[j] = gload4(base + (size_t)gr * ld + gk, gk, K, gr < rmax, vec_ok);
-        } else {
-            constexpr int Q = R / 4;
-            const int krow = i / Q, cq = i % Q;
-            const int gk = k0 + krow, gc = r0 + 4 * cq;
-            reg[j] = gload4(base + (size_t)gk * ld + gc, gc, rmax, gk < K, vec_ok);
-        }
-    }
-}
-
-template <int R, int T, bool KM>
-__device__ __forceinline__ void stage_store(const f32x4 (&reg)[R / 32], float* __restrict__ s, int tid) {
-#pragma unroll
-    for (int j = 0; j < R / 32; ++j) {
-        const int i = tid + NTHR * j;
-        if (!KM) {
-            const int row = i >> 3, kq = i & 7;
-            *reinterpret_cast<f32x4*>(s + row * S_KC + 4 * kq) = reg[j];
-        } else {
-            constexpr int Q = R / 4;
-            constexpr int S = km_stride(R, T);
-            const int krow = i / Q, cq = i % Q;
-            *reinterpret_cast<f32x4*>(s + krow * S + 4 * cq) = reg[j];
-        }
-    }
-}
-
-// ---- fragment reads for one 16-k chunk: f[t][blk], t = MFMA step (k = 16c + 4q + t) ------------
-template <int R, int T, bool KM>
-__device__ __forceinline__ void read_frags(float (&f)[4][T], const float* __restrict__ s, int wave_off, int chunk,
-                                           int r, int q) {
-    if (!KM) {
+// One operand's fragments for the 16-k chunk c: f[t][b] (t = MFMA step, b = 16-row block).
+//   R = extent of the non-contracted dimension (rows are CLAMPED to R-1: they only feed outputs that
+//   the epilogue never stores), K = contracted extent (out-of-range k is ZERO-filled).
+//   FAST: the chunk is interior in k and the operand is 16-B aligned (wave-uniform, decided by caller).
+template <int T, bool KM, bool FAST>
+__device__ __forceinline__ void load_frag(float (&f)[4][T], const float* __restrict__ base, int ld, int off0, int R,
+                                          int K, int c, int r, int q) {
+    if (!KM) {  // memory [row][k]
 #pragma unroll
         for (int b = 0; b < T; ++b) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s + (wave_off + 16 * b + r) * S_KC + 16 * chunk + 4 * q);
+            int row = off0 + 16 * b + r;
+            row = row < R ? row : R - 1;
+            const float* p = base + (size_t)row * ld + 16 * c + 4 * q;
+            if (FAST) {
+                const f32x4 v = ldg<f32x4>(p);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) f[t][b] = v[t];
+                for (int t = 0; t < 4; ++t) f[t][b] = v[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f[t][b] = (16 * c + 4 * q + t < K) ? ldg<float>(p + t) : 0.f;
+            }
         }
-    } else {
-        constexpr int S = km_stride(R, T);
+    } else {  // memory [k][row]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const typename VecT<T>::type v =
-                *reinterpret_cast<const typename VecT<T>::type*>(s + (16 * chunk + 4 * q + t) * S + wave_off + T * r);
+            const int k = 16 * c + 4 * q + t;
+            const int col = off0 + T * r;
+            if (FAST && col + T <= R) {
+                const typename VecT<T>::type v = ldg<typename VecT<T>::type>(base + (size_t)k * ld + col);
 #pragma unroll
-            for (int b = 0; b < T; ++b) f[t][b] = vget<T>(v, b);
+                for (int b = 0; b < T; ++b) f[t][b] = vget<T>(v, b);
+            } else {
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    int cc = col + b;
+                    cc = cc < R ? cc : R - 1;
+                    f[t][b] = (k < K) ? ldg<float>(base + (size_t)k * ld + cc) : 0.f;
+                }
+            }
         }
     }
 }
@@ -125,21 +96,26 @@ __device__ __forceinline__ void read_frags(float (&f)[4][T], const float* __rest
 template <int T, bool KM>
 __device__ __forceinline__ int slot_index(int blk, int slot) { return KM ? T * slot + blk : 16 * blk + slot; }
 
-template <int TM, int TN, bool AKM, bool BKM>
+template <int TM, int TN, int WM, int WN, int KS, int D, bool AKM, bool BKM>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, float* __restrict__ smem) {
-    constexpr int RA = 32 * TM, RB = 32 * TN;
-    constexpr int FA = tile_floats(AKM, RA, TM), FB = tile_floats(BKM, RB, TN);
+    static_assert(WM * WN * KS == 4, "4 waves per workgroup");
+    constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wave / (WM * WN), ws = wave % (WM * WN);
+    const int wm = ws / WN, wn = ws % WN;
     const int r = lane & 15, q = lane >> 4;
     const int M = d.M, N = d.N, K = d.K;
-    const int m0 = tm * RA, n0 = tn * RB;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int am = m0 + wm * 16 * TM, bn = n0 + wn * 16 * TN;
     const float* __restrict__ A = d.A;
     const float* __restrict__ B = d.B;
-    const bool vecA = ((d.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    const bool vecB = ((d.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-
+    const int lda = d.lda, ldb = d.ldb;
+    // vector loads need 16-B aligned bases and row pitches
+    const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const bool vec = vecA && vecB;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -151,97 +127,164 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     for (int m = 0; m < TM; ++m) csum[m] = 0.f;
     const bool do_colsum = AKM && (d.colsum != nullptr) && (tn == 0) && (wn == 0);
 
-    f32x4 ra[RA / 32], rb[RB / 32];
-    const int nk = (K + BK - 1) / BK;
-    stage_load<RA, AKM>(ra, A, d.lda, m0, M, 0, K, vecA, tid);
-    stage_load<RB, BKM>(rb, B, d.ldb, n0, N, 0, K, vecB, tid);
-    stage_store<RA, TM, AKM>(ra, smem, tid);
-    stage_store<RB, TN, BKM>(rb, smem + FA, tid);
-    __syncthreads();
+    // this wave's chunk range [cbeg, cend) of the ceil(K/16) chunks
+    const int nc = (K + 15) >> 4;
+    const int per = (nc + KS - 1) / KS;
+    const int cbeg = ks * per;
+    const int cend = (cbeg + per < nc) ? cbeg + per : nc;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* __restrict__ curA = smem + (kt & 1) * (FA + FB);
-        const float* __restrict__ curB = curA + FA;
-        float* __restrict__ nxtA = smem + ((kt + 1) & 1) * (FA + FB);
-        const bool more = kt + 1 < nk;
-        if (more) {
-            stage_load<RA, AKM>(ra, A, d.lda, m0, M, (kt + 1) * BK, K, vecA, tid);
-            stage_load<RB, BKM>(rb, B, d.ldb, n0, N, (kt + 1) * BK, K, vecB, tid);
+    float fa[D][4][TM], fb[D][4][TN];
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][t][m], fb[s][t][n], acc[m][n], 0, 0, 0);
         }
+        if (do_colsum) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float fa[4][TM], fb[4][TN];
-            read_frags<RA, TM, AKM>(fa, curA, wm * 16 * TM, c, r, q);
-            read_frags<RB, TN, BKM>(fb, curB, wn * 16 * TN, c, r, q);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+                for (int m = 0; m < TM; ++m) csum[m] += fa[s][t][m];
+        }
+    };
+
+    int c = cbeg;
+    if (vec) {
+        // fast region: whole groups of D chunks that are interior in k -- straight-line code, the next
+        // group's loads issued right behind the MFMAs that free their registers, counted vmcnt waits
+        const int cf_end = cend < (K >> 4) ? cend : (K >> 4);
+        const int nfull = cf_end > cbeg ? (cf_end - cbeg) / D : 0;
+        if (nfull > 0) {
 #pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t][m], fb[t][n], acc[m][n], 0, 0, 0);
+            for (int s = 0; s < D; ++s) {
+                load_frag<TM, AKM, true>(fa[s], A, lda, am, M, K, cbeg + s, r, q);
+                load_frag<TN, BKM, true>(fb[s], B, ldb, bn, N, K, cbeg + s, r, q);
             }
-            if (do_colsum) {
+            for (int g = 1; g < nfull; ++g) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < D; ++s) {
+                    mma(s);
+                    load_frag<TM, AKM, true>(fa[s], A, lda, am, M, K, cbeg + g * D + s, r, q);
+                    load_frag<TN, BKM, true>(fb[s], B, ldb, bn, N, K, cbeg + g * D + s, r, q);
+                }
+            }
 #pragma unroll
-                    for (int m = 0; m < TM; ++m) csum[m] += fa[t][m];
+            for (int s = 0; s < D; ++s) mma(s);
+            c = cbeg + nfull * D;
+        }
+    }
+    // remainder (ragged k, a partial last group, or unaligned operands): guarded loads, group by group
+    for (; c < cend; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            if (c + s < cend) {
+                load_frag<TM, AKM, false>(fa[s], A, lda, am, M, K, c + s, r, q);
+                load_frag<TN, BKM, false>(fb[s], B, ldb, bn, N, K, c + s, r, q);
             }
         }
-        if (more) {
-            stage_store<RA, TM, AKM>(ra, nxtA, tid);
-            stage_store<RB, TN, BKM>(rb, nxtA + FA, tid);
-        }
-        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (c + s < cend) mma(s);
     }
 
-    // ---- epilogue: acc[m][n][j] is (row slot 4q+j, col slot r) of block (m,n) ----
-    const int epi = d.epi;
-    float* __restrict__ C = d.C;
-    const float* __restrict__ aux = d.aux;
+    // ---- epilogue: k-slices meet in LDS ([KS][BM][BN+4]), summed in fixed order; whole rows leave ----
+    constexpr int SC = BN + 4;
+    float* __restrict__ Cs = smem + ks * (BM * SC);
 #pragma unroll
-    for (int m = 0; m < TM; ++m) {
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = m0 + wm * 16 * TM + slot_index<TM, AKM>(m, 4 * q + j);
-            if (row >= M) continue;
+            const int lr = wm * 16 * TM + slot_index<TM, AKM>(m, 4 * q + j);
 #pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const int col = n0 + wn * 16 * TN + slot_index<TN, BKM>(n, r);
-                if (col >= N) continue;
-                float v = acc[m][n][j];
-                const size_t o = (size_t)row * d.ldc + col;
-                if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) {
-                    v += aux[col];
-                    if (d.ctab) {
-                        const int g = d.gender[row], a = d.age[row];
-                        if (g >= 0 && g < 3) v += d.ctab[(size_t)g * N + col];
-                        if (a >= 0 && a < 3) v += d.ctab[(size_t)(3 + a) * N + col];
-                    }
-                    if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                } else if (epi == EPI_MASK) {
-                    v = aux[o] > 0.f ? v : 0.f;
-                } else if (epi == EPI_ACCUM) {
-                    v += C[o];
-                }
-                C[o] = v;
-            }
+            for (int n = 0; n < TN; ++n) Cs[lr * SC + wn * 16 * TN + slot_index<TN, BKM>(n, r)] = acc[m][n][j];
         }
-    }
+    float* __restrict__ csum_s = smem + KS * (BM * SC);  // [KS][BM] bias-gradient partials
     if (do_colsum) {
-        // lanes with equal r hold partial sums over k = 4q+t (q = lane>>4): reduce over q
+        // lanes with equal r hold partial sums over k = 4q+t: reduce over q, then park per k-slice
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
             float s = csum[m];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            const int row = m0 + wm * 16 * TM + slot_index<TM, true>(m, r);
-            if (q == 0 && row < M) d.colsum[row] = s;
+            if (q == 0) csum_s[ks * BM + wm * 16 * TM + slot_index<TM, true>(m, r)] = s;
         }
+    }
+    __syncthreads();
+    const int epi = d.epi;
+    float* __restrict__ C = d.C;
+    const float* __restrict__ aux = d.aux;
+    const int ldc = d.ldc;
+    const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
+    constexpr int CQ = BN / 4;        // float4 per tile row
+    constexpr int RSTEP = NTHR / CQ;  // rows per pass (CQ <= 32 for every config)
+    const int c4 = tid % CQ, r0 = tid / CQ;
+    const int col = n0 + 4 * c4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < N) bias4[e] = ldg<float>(aux + col + e);
+    }
+#pragma unroll
+    for (int rr = 0; rr < BM; rr += RSTEP) {
+        const int lr = rr + r0;
+        const int row = m0 + lr;
+        if (lr >= BM || row >= M || col >= N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * SC + 4 * c4);
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 4 * c4);
+        const size_t o = (size_t)row * ldc + col;
+        const bool full = vecC && (col + 3 < N);
+        if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) {
+            v += bias4;
+            if (d.ctab) {
+                const int g = d.gender[row], a = d.age[row];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e < N) {
+                        if (g >= 0 && g < 3) v[e] += ldg<float>(d.ctab + (size_t)g * N + col + e);
+                        if (a >= 0 && a < 3) v[e] += ldg<float>(d.ctab + (size_t)(3 + a) * N + col + e);
+                    }
+                }
+            }
+            if (epi == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+        } else if (epi == EPI_MASK || epi == EPI_ACCUM) {
+            const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (full) {
+                w = ldg<f32x4>(src + o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) w[e] = ldg<float>(src + o + e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (epi == EPI_MASK) ? (w[e] > 0.f ? v[e] : 0.f) : v[e] + w[e];
+        }
+        if (full) {
+            stg<f32x4>(C + o, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < N) stg<float>(C + o + e, v[e]);
+        }
+    }
+    if (AKM && d.colsum != nullptr && tn == 0 && tid < BM) {
+        float s = csum_s[tid];
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) s += csum_s[k2 * BM + tid];
+        if (m0 + tid < M) stg<float>(d.colsum + m0 + tid, s);
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int WM, int WN, int KS, int D>
 __global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
@@ -252,84 +295,122 @@ __global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batc
     const int lt = tile - d.tile_begin;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
     if (d.kind == GK_NT)
-        gemm_tile<TM, TN, false, false>(d, tm, tn, smem);
+        gemm_tile<TM, TN, WM, WN, KS, D, false, false>(d, tm, tn, smem);
     else if (d.kind == GK_NN)
-        gemm_tile<TM, TN, false, true>(d, tm, tn, smem);
+        gemm_tile<TM, TN, WM, WN, KS, D, false, true>(d, tm, tn, smem);
     else
-        gemm_tile<TM, TN, true, true>(d, tm, tn, smem);
+        gemm_tile<TM, TN, WM, WN, KS, D, true, true>(d, tm, tn, smem);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+struct Cfg {
+    int TM, TN, WM, WN, KS, D;
+    float eff;  // measured MFMA-issue efficiency of the wave tile (fragment reuse)
+};
+// index + 1 = config id (what psvae_gemm_f32's `tile` / psvae_debug_force_tile select)
+static const Cfg kCfgs[] = {
+    {2, 2, 1, 1, 4, 4, 0.80f},  // 1: 32x32  tile, k split 4
+    {2, 4, 1, 1, 4, 4, 0.90f},  // 2: 32x64  tile, k split 4
+    {4, 2, 1, 1, 4, 4, 0.90f},  // 3: 64x32  tile, k split 4
+    {2, 2, 1, 2, 2, 4, 0.80f},  // 4: 32x64  tile, k split 2
+    {2, 2, 2, 2, 1, 4, 0.80f},  // 5: 64x64  tile, no split
+    {4, 4, 1, 1, 4, 2, 0.95f},  // 6: 64x64  tile, k split 4
+    {4, 4, 2, 2, 1, 2, 0.95f},  // 7: 128x128 tile, no split (large batches)
+    {1, 2, 1, 1, 4, 4, 0.60f},  // 8: 16x32  tile, k split 4 (tiny outputs)
+    {4, 4, 1, 2, 2, 2, 0.95f},  // 9: 64x128 tile, k split 2
+};
+constexpr int NCFG = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+static int g_forced = -1;  // -1: read PSVAE_TILE once; the tuning hook psvae_debug_force_tile overrides
+void debug_force_tile(int cfg) { g_forced = cfg; }
+void debug_set_flags(int) {}
 
-static int count_tiles(const GemmBatch& b, int TM, int TN) {
-    int t = 0;
-    for (int i = 0; i < b.n; ++i) t += ((b.d[i].M + 32 * TM - 1) / (32 * TM)) * ((b.d[i].N + 32 * TN - 1) / (32 * TN));
-    return t;
+// Cost model (cycles): each workgroup occupies all 4 SIMDs of a CU; per-wave MFMA cycles =
+// blocks * ksteps * 32 / eff; a launch lasts about max(longest workgroup, per-CU share).
+static double estimate(const GemmBatch& b, const Cfg& c) {
+    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+    double total = 0, longest = 0;
+    long tiles = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const GemmDesc& d = b.d[i];
+        const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+        const int chunks = (d.K + 15) / 16;
+        const int per = ((chunks + c.KS - 1) / c.KS + c.D - 1) / c.D * c.D;  // padded to whole groups
+        const double cyc = per * 4.0 * c.TM * c.TN * 32.0 / c.eff + 2500.0;    // + prologue/epilogue
+        total += t * cyc;
+        longest = cyc > longest ? cyc : longest;
+        tiles += t;
+    }
+    const double rounds = (double)((tiles + 255) / 256);
+    const double share = total / 256.0 * (rounds * 256.0 / (double)tiles);  // quantisation of the last round
+    return share > longest ? share : longest;
 }
 
 int pick_tile(const GemmBatch& b) {
-    static const int min_tiles = env_int("PSVAE_MIN_TILES", 384);
-    static const int forced = env_int("PSVAE_TILE", 0);
-    if (forced) return forced;
-    int maxM = 0, maxN = 0;
-    for (int i = 0; i < b.n; ++i) {
-        maxM = b.d[i].M > maxM ? b.d[i].M : maxM;
-        maxN = b.d[i].N > maxN ? b.d[i].N : maxN;
+    if (g_forced < 0) g_forced = env_int("PSVAE_TILE", 0);
+    if (g_forced > 0 && g_forced <= NCFG) return g_forced;
+    int best = 1;
+    double bc = 1e30;
+    for (int i = 0; i < NCFG; ++i) {
+        const double e = estimate(b, kCfgs[i]);
+        if (e < bc) { bc = e; best = i + 1; }
     }
-    static const int cand[][2] = {{4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
-    for (auto& c : cand) {
-        const int TM = c[0], TN = c[1];
-        if (32 * TM > ((maxM + 31) / 32) * 32 || 32 * TN > ((maxN + 31) / 32) * 32) continue;
-        if (count_tiles(b, TM, TN) >= min_tiles) return (TM << 4) | TN;
-    }
-    return (1 << 4) | 1;
+    return best;
 }
 
-void finalize_batch(GemmBatch& b, int tile) {
-    const int TM = tile >> 4, TN = tile & 15;
+void finalize_batch(GemmBatch& b, int cfg) {
+    const Cfg& c = kCfgs[cfg - 1];
+    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
-        b.d[i].tiles_m = (b.d[i].M + 32 * TM - 1) / (32 * TM);
-        b.d[i].tiles_n = (b.d[i].N + 32 * TN - 1) / (32 * TN);
+        b.d[i].tiles_m = (b.d[i].M + BM - 1) / BM;
+        b.d[i].tiles_n = (b.d[i].N + BN - 1) / BN;
         b.d[i].tile_begin = t;
         t += b.d[i].tiles_m * b.d[i].tiles_n;
     }
     b.total_tiles = t;
+    b.dbg = 0;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int WM, int WN, int KS, int D>
 static hipError_t launch_cfg(const GemmBatch& b, hipStream_t stream) {
-    constexpr size_t lds = 2 * pair_floats(TM, TN) * sizeof(float);
+    constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
+    constexpr size_t lds = (size_t)(KS * BM * (BN + 4) + KS * BM) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<TM, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<TM, TN, WM, WN, KS, D>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_kernel<TM, TN>), dim3(b.total_tiles), dim3(NTHR), lds, stream, b);
+    hipLaunchKernelGGL((gemm_grouped_kernel<TM, TN, WM, WN, KS, D>), dim3(b.total_tiles), dim3(NTHR), lds, stream, b);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_batch(GemmBatch& b, int tile, hipStream_t stream) {
+hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
-    if (tile == 0) tile = pick_tile(b);
-    finalize_batch(b, tile);
+    if (cfg == 0) cfg = pick_tile(b);
+    if (cfg < 1 || cfg > NCFG) return hipErrorInvalidValue;
+    finalize_batch(b, cfg);
     if (b.total_tiles == 0) return hipSuccess;
-    switch (tile) {
-        case 0x44: return launch_cfg<4, 4>(b, stream);
-        case 0x42: return launch_cfg<4, 2>(b, stream);
-        case 0x24: return launch_cfg<2, 4>(b, stream);
-        case 0x22: return launch_cfg<2, 2>(b, stream);
-        case 0x21: return launch_cfg<2, 1>(b, stream);
-        case 0x12: return launch_cfg<1, 2>(b, stream);
-        case 0x11: return launch_cfg<1, 1>(b, stream);
+    switch (cfg) {
+        case 1: return launch_cfg<2, 2, 1, 1, 4, 4>(b, stream);
+        case 2: return launch_cfg<2, 4, 1, 1, 4, 4>(b, stream);
+        case 3: return launch_cfg<4, 2, 1, 1, 4, 4>(b, stream);
+        case 4: return launch_cfg<2, 2, 1, 2, 2, 4>(b, stream);
+        case 5: return launch_cfg<2, 2, 2, 2, 1, 4>(b, stream);
+        case 6: return launch_cfg<4, 4, 1, 1, 4, 2>(b, stream);
+        case 7: return launch_cfg<4, 4, 2, 2, 1, 2>(b, stream);
+        case 8: return launch_cfg<1, 2, 1, 1, 4, 4>(b, stream);
+        case 9: return launch_cfg<4, 4, 1, 2, 2, 2>(b, stream);
         default: return hipErrorInvalidValue;
     }
 }
+
+int num_gemm_configs() { return NCFG; }
 
 }  // namespace psvae

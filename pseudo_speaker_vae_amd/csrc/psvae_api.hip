@@ -70,6 +70,12 @@ extern "C" {
 
 int psvae_version(void) { return PSVAE_ABI_VERSION; }
 
+int psvae_debug_force_tile(int tile) {
+    if (tile < 0 || tile > num_gemm_configs()) return PSVAE_ERR_ARG;
+    debug_force_tile(tile);
+    return 0;
+}
+
 const char* psvae_strerror(int code) {
     switch (code) {
         case PSVAE_OK: return "ok";
@@ -101,11 +107,7 @@ int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, in
     if (M <= 0 || N <= 0 || K <= 0) return PSVAE_ERR_SHAPE;
     if (kind < 0 || kind > 2 || epi < 0 || epi > 4) return PSVAE_ERR_ARG;
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_MASK) && !bias_or_mask) return PSVAE_ERR_NULL;
-    if (tile != 0) {
-        const int TM = tile >> 4, TN = tile & 15;
-        if (!((TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4))) return PSVAE_ERR_ARG;
-        if (TM * TN == 4 && TM != TN) return PSVAE_ERR_ARG;  // 4x1 / 1x4 not instantiated
-    }
+    if (tile < 0 || tile > num_gemm_configs()) return PSVAE_ERR_ARG;
     GemmBatch b{};
     add(b, make_desc(kind, (int)M, (int)N, (int)K, A, (int)lda, B, (int)ldb, C, (int)ldc, epi, bias_or_mask,
                      kind == GK_TN ? colsum : nullptr));

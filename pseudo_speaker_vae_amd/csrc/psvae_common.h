@@ -44,13 +44,16 @@ struct GemmBatch {
     GemmDesc d[MAX_GROUP];
     int n;
     int total_tiles;
+    int dbg;  // reserved (0)
 };
 
-// tile = (TM << 4) | TN with TM,TN in {1,2,4}: workgroup tile (32*TM) x (32*TN), 4 waves as 2x2.
-// tile == 0 picks one from the problem sizes (see pick_tile).
+// cfg = 1..num_gemm_configs() selects a (wave tile, wave layout, k-split, prefetch depth) config
+// (table in gemm_f32.hip); cfg == 0 picks one from the problem sizes with a cost model (pick_tile).
 int pick_tile(const GemmBatch& b);
-void finalize_batch(GemmBatch& b, int tile);
-hipError_t launch_gemm_batch(GemmBatch& b, int tile, hipStream_t stream);
+int num_gemm_configs();
+void debug_force_tile(int cfg);  // 0 = automatic
+void finalize_batch(GemmBatch& b, int cfg);
+hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream);
 
 inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                           float* C, int ldc, int epi, const float* aux, float* colsum = nullptr) {

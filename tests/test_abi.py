@@ -36,6 +36,8 @@ def test_argument_errors_before_any_launch(lib):
     assert lib.psvae_philox_normal_f32(None, 16, 0, 0, None) == -1
     assert lib.psvae_gemm_f32(0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, 0, None) == -1
     assert lib.psvae_gemm_f32(7, 4, 4, 4, 16, 4, 16, 4, 16, 4, None, None, 0, 0, None) == -4
+    assert lib.psvae_gemm_f32(0, 4, 4, 4, 16, 4, 16, 4, 16, 4, None, None, 0, 99, None) == -4
+    assert lib.psvae_debug_force_tile(99) == -4 and lib.psvae_debug_force_tile(0) == 0
     assert lib.psvae_gemm_f32(0, 0, 4, 4, 16, 4, 16, 4, 16, 4, None, None, 0, 0, None) == -2
     d = _ffi.Dims(0, 256, 64)
     assert lib.psvae_scratch_bytes(C.byref(d)) == 0

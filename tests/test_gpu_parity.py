@@ -35,8 +35,24 @@ def run_step(ops, p, x, eps, beta, normalize, cos, go=None, seed=None):
     god = torch.tensor([go], device=DEV) if go is not None else None
     ops.vae_backward(ws, xd, params, xh, mu, lv, grads, elbo_grad=True, beta=beta, grad_loss=god, flags=flags)
     torch.cuda.synchronize()
+    masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
     return dict(x_hat=xh.cpu(), mu=mu.cpu(), logvar=lv.cpu(), z=ws.acts["z"].cpu(), eps=ws.acts["eps"].cpu(),
-                loss3=loss3.cpu(), grads={k: g.cpu() for k, g in zip(O.PARAM_KEYS, grads)}, ws=ws)
+                loss3=loss3.cpu(), grads={k: g.cpu() for k, g in zip(O.PARAM_KEYS, grads)}, ws=ws, masks=masks)
+
+
+MASK_KEYS = ("h1m", "h2m", "h1s", "h2s", "d1", "d2")
+
+
+def check_masks(gpu_masks, oracle_acts):
+    """ReLU masks of the HIP path may differ from the oracle's only at activations within fp32
+    rounding of zero (the ReLU kink), and only for a vanishing fraction of elements."""
+    for k in MASK_KEYS:
+        ref = oracle_acts[k]
+        diff = gpu_masks[k] != (ref > 0)
+        n = int(diff.sum())
+        assert n <= max(2, 2e-5 * ref.numel()), f"{k}: {n} mask flips"
+        if n:
+            assert float(ref[diff].abs().max()) <= 2e-5 * float(ref.abs().max()), f"{k}: flip at a non-tiny activation"
 
 
 @pytest.mark.parametrize("path", step_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
@@ -65,7 +81,9 @@ def test_train_step_matches_oracle(ops, D, Z, B, variant):
     x, eps = torch.randn(B, D), torch.randn(B, Z)
     go = 0.37
     out = run_step(ops, p, x, eps, 0.8, normalize, cos, go=go)
-    losses, grads, acts, _ = O.train_step(p, x, eps, 0.8, normalize, cos, go=go)
+    # gradients are compared at equal ReLU masks (see oracle.backward): the masks themselves are checked
+    losses, grads, acts, _ = O.train_step(p, x, eps, 0.8, normalize, cos, go=go, masks=out["masks"])
+    check_masks(out["masks"], acts)
     for k in ("x_hat", "mu", "logvar", "z"):
         assert_close(out[k], acts[k], REL_TOL, k)
     for i, k in enumerate(("total", "recon", "kl")):
@@ -148,7 +166,9 @@ def test_decode_matches_reference_golden(ops, name):
 
 
 def test_decode_chunked_large(ops):
-    """more rows than one internal chunk (65536): rows are independent, so any slice must equal a direct decode."""
+    """more rows than one internal chunk (65536): rows are independent, so any slice must match a direct
+    decode of those rows (to rounding: a different batch size may pick a different k-split, i.e. a
+    different fp32 summation order)."""
     D, Z, N = 256, 64, 70000
     p = O.init_params(D, Z, 0)
     dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
@@ -156,7 +176,7 @@ def test_decode_chunked_large(ops):
     full = ops.decode(z, dec, D)
     part = ops.decode(z[65500:65600].contiguous(), dec, D)
     torch.cuda.synchronize()
-    assert torch.equal(full[65500:65600], part)
+    assert_close(full[65500:65600].cpu(), part.cpu(), 2e-6, "chunk seam rows")
     ref = O.decode(p, z[-64:].cpu())
     assert_close(full[-64:].cpu(), ref, REL_TOL, "decode tail")
 
