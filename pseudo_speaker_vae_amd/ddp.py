@@ -1,0 +1,54 @@
+"""Data-parallel gradient averaging for the hot path (the reference's DDPStrategy, training.py:78).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
+tests).  Gradients live in ONE flat buffer laid out [encoders | 3 loss scalars | decoder]; the
+averager issues one asynchronous all-reduce per bucket, in the order backward produces them
+(decoder first), so the first collective runs under the remaining backward kernels.  The loss
+scalars ride in the encoder bucket: that replaces Lightning's one-scalar-per-logged-key
+`sync_dist` all-reduces (lightning.py:127-129).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class GradAverager:
+    def __init__(self, flat: torch.Tensor, bucket_bounds: Sequence[int], process_group=None):
+        """flat: the flat gradient buffer; bucket_bounds: ascending offsets [0, b1, ..., len(flat)]."""
+        assert bucket_bounds[0] == 0 and bucket_bounds[-1] == flat.numel()
+        self.flat = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets: List[torch.Tensor] = [flat[a:b] for a, b in zip(bucket_bounds[:-1], bucket_bounds[1:])]
+        self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._pending: List = []
+        self._needs_scale: List[int] = []
+
+    def reduce_bucket(self, i: int):
+        """start averaging bucket i (asynchronously); call once the kernels that WRITE it are enqueued"""
+        if self.world == 1:
+            return
+        if self.backend == "nccl":  # RCCL: averaging inside the collective
+            w = dist.all_reduce(self.buckets[i], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:
+            w = dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._needs_scale.append(i)
+        self._pending.append(w)
+
+    def wait(self):
+        """make the current stream (or the host, for gloo) wait for every started bucket"""
+        for w in self._pending:
+            w.wait()
+        for i in self._needs_scale:
+            self.buckets[i].mul_(1.0 / self.world)
+        self._pending.clear()
+        self._needs_scale.clear()
+
+
+def broadcast_flat(flat: torch.Tensor, src: int = 0, process_group=None):
+    """initial parameter sync (DDP's rank-0 broadcast); a no-op on one rank"""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat, src=src, group=process_group)

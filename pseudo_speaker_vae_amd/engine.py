@@ -17,6 +17,7 @@ from typing import List, Optional
 import torch
 
 from . import _ffi, ops
+from .ddp import GradAverager, broadcast_flat
 from .model import VAEModel
 
 ALIGN = 64  # floats (256 B)
@@ -82,8 +83,11 @@ class TrainEngine:
         for dst, s in zip(self.params, src):
             dst.copy_(s)
         self.loss3 = self.flat_grads[self.layout.loss_offset:self.layout.loss_offset + 3]
-        self.enc_bucket = self.flat_grads[:self.layout.enc_end]
-        self.dec_bucket = self.flat_grads[self.layout.enc_end:]
+        # bucket 0 = encoders + loss scalars, bucket 1 = decoder (reduced first: its grads are ready first)
+        self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group) \
+            if self.world > 1 else None
+        if self.world > 1:
+            broadcast_flat(self.flat_params, 0, process_group)
         self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
         self.outs = self.ws.new_outputs()
         self.step_count = 0
@@ -106,24 +110,13 @@ class TrainEngine:
             ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
                              flags=self.flags)
             return
-        import torch.distributed as dist
         ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
                          flags=self.flags, phases=_ffi.PHASE_DECODER)
-        w1 = self._allreduce(self.dec_bucket)          # runs under the encoder backward
+        self.averager.reduce_bucket(1)                 # decoder grads: runs under the encoder backward
         ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
                          flags=self.flags, phases=_ffi.PHASE_ENCODER)
-        w2 = self._allreduce(self.enc_bucket)          # + the 3 loss scalars
-        w1.wait()
-        w2.wait()
-        if self._sum_only:
-            self.flat_grads.mul_(1.0 / self.world)
-
-    def _allreduce(self, t: torch.Tensor):
-        import torch.distributed as dist
-        backend = dist.get_backend(self.pg)
-        self._sum_only = backend != "nccl"
-        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
-        return dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+        self.averager.reduce_bucket(0)                 # encoder grads + the 3 loss scalars
+        self.averager.wait()
 
     def optimizer_step(self, lr: Optional[float] = None):
         """fused Adam over the flat buffers (lightning.py:205)."""

@@ -172,22 +172,21 @@ class ELBOStepFunction(torch.autograd.Function):
 
 
 class DecodeFunction(torch.autograd.Function):
-    """x_hat = decoder(z); differentiable w.r.t. z and the decoder parameters through the same kernels."""
+    """x_hat = decoder(z) on the HIP decode path.  The reference only ever detaches the result
+    (inference.py:25,105), so the forward is always available; a backward through decode() is not
+    part of the hot path and raises."""
 
     @staticmethod
     def forward(ctx, z, flags, *dec):
         if not z.is_cuda:
             raise _ffi.PsvaeError("VAEModel.decode runs on the GPU only (HIP kernels)")
         dec = [p.detach() for p in dec]
-        D = dec[4].shape[0]
-        ctx.set_materialize_grads(False)
-        if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:]):
-            raise _ffi.PsvaeError("decode() under autograd is not supported yet: wrap the call in torch.no_grad()")
-        return ops.decode(z.detach().float(), dec, D, flags)
+        return ops.decode(z.detach().float(), dec, dec[4].shape[0], flags)
 
     @staticmethod
     def backward(ctx, g):  # pragma: no cover
-        raise _ffi.PsvaeError("decode() backward is not implemented")
+        raise _ffi.PsvaeError("backward through VAEModel.decode() is not implemented (the reference detaches it); "
+                              "use forward()/elbo_step() for training")
 
 
 class VAEModel(nn.Module):

@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference interface, checked without a GPU: names, shapes, init order,
+hparams access, checkpoint round trip, label maps, flat layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load
+from oracle import psvae_oracle as O
+
+
+def test_vaemodel_state_dict_matches_reference_layout():
+    from ps_vae.model import PsVAE, VAEModel
+    assert PsVAE is VAEModel
+    m = VAEModel(256, 64)
+    sd = m.state_dict()
+    assert tuple(sd.keys()) == O.PARAM_KEYS                      # model.py:14-36 names, creation order
+    shapes = O.param_shapes(256, 64)
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], k
+    assert sum(v.numel() for v in sd.values()) == 1_281_408
+    assert [p is q for p, q in zip(m.ordered_params(), m.parameters())] == [True] * 18
+    d = VAEModel()                                                # defaults of model.py:8
+    assert (d.input_dim, d.latent_dim, d.normalize_decoder) == (512, 64, False)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3])
+def test_default_init_consumes_rng_like_the_reference(seed):
+    """fixtures assert oracle.init_params == the reference's parameters bit for bit (make_golden.py);
+    here the product's module must equal oracle.init_params bit for bit."""
+    from ps_vae.model import VAEModel
+    torch.manual_seed(seed)
+    m = VAEModel(256, 32)
+    ref = O.init_params(256, 32, seed)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
+def test_lightning_module_surface():
+    from ps_vae.lightning import PseudoSpeakerVAE
+    hp = dict(model=dict(input_dim=256, latent_dim=64, normalize_decoder=False), kl_loss_weight=0.5,
+              use_cos_loss=True, optimizer=dict(lr=2e-3), scheduler=dict(T_max=7, eta_min=1e-5))
+    m = PseudoSpeakerVAE(**hp)
+    assert m.hparams["optimizer"] == dict(lr=2e-3) and m.hparams.model["latent_dim"] == 64
+    assert (m.kl_loss_weight, m.classifier_loss_weight, m.consitency_loss_weight, m.use_cos_loss) == (0.5, 1.0, 1.0, True)
+    assert m.classifier is None and m.consistency_classifier is None
+    assert all(k.startswith("model.") for k in m.state_dict())
+    cfg = m.configure_optimizers()                                # lightning.py:204-214
+    assert isinstance(cfg["optimizer"], torch.optim.Adam)
+    assert cfg["lr_scheduler"]["interval"] == "epoch" and cfg["lr_scheduler"]["frequency"] == 1
+    assert isinstance(cfg["lr_scheduler"]["scheduler"], torch.optim.lr_scheduler.CosineAnnealingLR)
+    with pytest.raises(Exception, match="GPU only"):
+        m(torch.zeros(2, 256))                                    # no CPU fallback
+
+
+def test_classifier_state_dict_keys():
+    from ps_vae.latent_classifier import LatentClassifier
+    c = LatentClassifier(64, 3, num_layers=3, hidden_dim=128, activation="relu")
+    assert list(c.state_dict().keys()) == ["layers.0.weight", "layers.0.bias", "layers.2.weight", "layers.2.bias",
+                                           "layers.4.weight", "layers.4.bias"]
+    mh = LatentClassifier(256, {"label1": 10, "label2": 5}, 2, 128, "relu")  # latent_classifier.py:72-82 smoke
+    out = mh(torch.randn(32, 256))
+    assert out["label1"].shape == (32, 10) and out["label2"].shape == (32, 5)
+    with pytest.raises(ValueError):
+        LatentClassifier(4, 2, activation="gelu")
+
+
+def test_checkpoint_round_trip_and_partial_vae_load(tmp_path):
+    from ps_vae.lightning import PseudoSpeakerVAE
+    hp = dict(model=dict(input_dim=64, latent_dim=16), classifier=dict(input_dim=16, num_classes=3, num_layers=2,
+                                                                      hidden_dim=32, activation="relu"))
+    torch.manual_seed(0)
+    a = PseudoSpeakerVAE(**hp)
+    path = os.path.join(tmp_path, "best-checkpoint.ckpt")
+    a.save_checkpoint(path)
+    b = PseudoSpeakerVAE.load_from_checkpoint(path)               # inference.py:134
+    for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    assert b.hparams.model["latent_dim"] == 16
+    torch.manual_seed(5)
+    c = PseudoSpeakerVAE(model=dict(input_dim=64, latent_dim=16), vae_checkpoint=path, freeze_vae=True)  # lightning.py:18-25
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(c.model.state_dict()[k], v)
+    assert not any(p.requires_grad for p in c.model.parameters())
+
+
+def test_label_maps_match_reference_fixture():
+    from ps_vae.utils import METADATA_TRANSFORMS, map_cv_age_to_label, map_cv_gender_to_label, map_vctk_gender_to_label
+    fx = load(os.path.join(GOLDEN, "label_maps.npz"))
+    for s, none, lab in zip(fx["ages"], fx["age_is_none"], fx["age_labels"]):
+        assert map_cv_age_to_label(None if none else str(s)) == int(lab)
+    for s, none, cv, vc in zip(fx["genders"], fx["gender_is_none"], fx["cv_gender_labels"], fx["vctk_gender_labels"]):
+        key = None if none else str(s)
+        assert map_cv_gender_to_label(key) == int(cv) and map_vctk_gender_to_label(key) == int(vc)
+    assert METADATA_TRANSFORMS["age_and_gender"]({"age": "fifties", "gender": "female"}) == {"age": 1, "gender": 1}
+
+
+def test_flat_layout_buckets():
+    from pseudo_speaker_vae_amd.engine import FlatLayout
+    shapes = [torch.Size(s) for s in O.param_shapes(256, 64).values()]
+    lay = FlatLayout(shapes)
+    flat = torch.arange(lay.total, dtype=torch.float32)
+    views = lay.views(flat)
+    assert [tuple(v.shape) for v in views] == [tuple(s) for s in shapes]
+    assert all(o % 64 == 0 for o in lay.offsets)                  # 256-B aligned
+    assert lay.offsets[11] < lay.loss_offset < lay.enc_end <= lay.offsets[12]  # encoders | loss | decoder
+    # views do not overlap
+    ends = [o + s.numel() for o, s in zip(lay.offsets, shapes)]
+    assert all(e <= o2 for e, o2 in zip(ends[:-1], lay.offsets[1:]))

@@ -147,18 +147,28 @@ void run(const char* name, int M, int N, int K, float* dA, float* dB, float* dC)
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     const double usg = ms / (4 * reps) * 1e3;
-    printf("%-22s %4dx%4dx%4d grid %4d : eager %6.2f us graph %6.2f us  (%5.1f TF in graph)  maxerr %.1e\n", name, M, N, K, grid, us, usg,
-           2.0 * M * N * K / (usg * 1e-6) / 1e12, maxerr);
+    // cold L2: every launch reads a different copy of A and B (16 sets x 8 MB > 32 MB of L2)
+    const int NSETS = 16; const size_t SETSTRIDE = 1024 * 1024;
+    hipEventRecord(e0, 0);
+    for (int w = 0; w < 64; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA + (w % NSETS) * SETSTRIDE, dB + (w % NSETS) * SETSTRIDE, dC, M, N, K, lda, ldb, N);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    const double usc = ms / 64 * 1e3;
+    printf("%-22s %4dx%4dx%4d grid %4d : hot %6.2f us  graph %6.2f us  cold-L2 %6.2f us (%5.1f TF)  maxerr %.1e\n", name, M, N, K, grid, us, usg,
+           usc, 2.0 * M * N * K / (usc * 1e-6) / 1e12, maxerr);
 }
 
 int main() {
     const int MAXE = 1024 * 1024;
+    const int NS = 17;
     hA.resize(MAXE); hB.resize(MAXE);
     srand(1);
     for (auto& v : hA) v = (rand() % 2001 - 1000) / 1000.f;
     for (auto& v : hB) v = (rand() % 2001 - 1000) / 1000.f;
     float *dA, *dB, *dC;
-    hipMalloc(&dA, MAXE * 4); hipMalloc(&dB, MAXE * 4); hipMalloc(&dC, MAXE * 4);
+    hipMalloc(&dA, (size_t)NS * MAXE * 4); hipMalloc(&dB, (size_t)NS * MAXE * 4); hipMalloc(&dC, MAXE * 4);
+    hipMemset(dA, 0, (size_t)NS * MAXE * 4); hipMemset(dB, 0, (size_t)NS * MAXE * 4);
     hipMemcpy(dA, hA.data(), MAXE * 4, hipMemcpyHostToDevice);
     hipMemcpy(dB, hB.data(), MAXE * 4, hipMemcpyHostToDevice);
     // forward-like NT: [1024,512] x [512,512]^T
