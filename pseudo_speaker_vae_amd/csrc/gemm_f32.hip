@@ -52,7 +52,8 @@ __device__ __forceinline__ void stg(float* p, const V& v) {
 // One operand's fragments for the 16-k chunk c: f[t][b] (t = MFMA step, b = 16-row block).
 //   R = extent of the non-contracted dimension (rows are CLAMPED to R-1: they only feed outputs that
 //   the epilogue never stores), K = contracted extent (out-of-range k is ZERO-filled).
-//   FAST: the chunk is interior in k and the operand is 16-B aligned (wave-uniform, decided by caller).
+//   FAST: the chunk is interior in k, the operand is 16-B aligned and -- for KM -- the wave's span of
+//   16*T rows lies inside R (all wave-uniform, decided by the caller: no per-lane branch on this path).
 template <int T, bool KM, bool FAST>
 __device__ __forceinline__ void load_frag(float (&f)[4][T], const float* __restrict__ base, int ld, int off0, int R,
                                           int K, int c, int r, int q) {
@@ -76,7 +77,7 @@ __device__ __forceinline__ void load_frag(float (&f)[4][T], const float* __restr
         for (int t = 0; t < 4; ++t) {
             const int k = 16 * c + 4 * q + t;
             const int col = off0 + T * r;
-            if (FAST && col + T <= R) {
+            if (FAST) {  // caller guarantees the wave's whole span [off0, off0 + 16T) lies inside R
                 const typename VecT<T>::type v = ldg<typename VecT<T>::type>(base + (size_t)k * ld + col);
 #pragma unroll
                 for (int b = 0; b < T; ++b) f[t][b] = vget<T>(v, b);
@@ -115,7 +116,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     // vector loads need 16-B aligned bases and row pitches
     const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-    const bool vec = vecA && vecB;
+    // KM vector loads additionally need the wave's whole span inside the matrix (else: guarded path)
+    const bool fastA = vecA && (!AKM || am + 16 * TM <= M);
+    const bool fastB = vecB && (!BKM || bn + 16 * TN <= N);
+    const bool vec = fastA && fastB;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -176,11 +180,16 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
             c = cbeg + nfull * D;
         }
     }
-    // remainder (ragged k, a partial last group, or unaligned operands): guarded loads, group by group
+    // remainder: a partial last group (vector loads while the chunk is interior in k), a k-ragged last
+    // chunk or unaligned operands (guarded scalar loads) -- one group at a time, loads then MFMAs
+    const int c_int = vec ? (K >> 4) : 0;  // chunks below this are interior and aligned
     for (; c < cend; c += D) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            if (c + s < cend) {
+            if (c + s < c_int && c + s < cend) {
+                load_frag<TM, AKM, true>(fa[s], A, lda, am, M, K, c + s, r, q);
+                load_frag<TN, BKM, true>(fb[s], B, ldb, bn, N, K, c + s, r, q);
+            } else if (c + s < cend) {
                 load_frag<TM, AKM, false>(fa[s], A, lda, am, M, K, c + s, r, q);
                 load_frag<TN, BKM, false>(fb[s], B, ldb, bn, N, K, c + s, r, q);
             }
@@ -284,7 +293,49 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     }
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D>
+// ---- configurations -------------------------------------------------------------------------------
+// id -> (wave tile TMxTN in 16x16 blocks, wave grid WMxWN, k slices KS, prefetch depth D)
+template <int ID> struct CfgT;
+#define PSVAE_CFG(ID, TM_, TN_, WM_, WN_, KS_, D_) \
+    template <> struct CfgT<ID> { static constexpr int TM = TM_, TN = TN_, WM = WM_, WN = WN_, KS = KS_, D = D_; }
+PSVAE_CFG(1, 2, 2, 1, 1, 4, 4);  // 32x32   tile, k split 4
+PSVAE_CFG(2, 2, 4, 1, 1, 4, 4);  // 32x64   tile, k split 4
+PSVAE_CFG(3, 4, 2, 1, 1, 4, 4);  // 64x32   tile, k split 4
+PSVAE_CFG(4, 2, 2, 1, 2, 2, 4);  // 32x64   tile, k split 2
+PSVAE_CFG(5, 2, 2, 2, 2, 1, 4);  // 64x64   tile, no split
+PSVAE_CFG(6, 4, 4, 1, 1, 4, 2);  // 64x64   tile, k split 4
+PSVAE_CFG(7, 4, 4, 2, 2, 1, 2);  // 128x128 tile, no split (large batches)
+PSVAE_CFG(8, 1, 2, 1, 1, 4, 4);  // 16x32   tile, k split 4 (small outputs, long k)
+PSVAE_CFG(9, 4, 4, 1, 2, 2, 2);  // 64x128  tile, k split 2
+constexpr int NCFG = 9;
+
+struct Cfg {
+    int TM, TN, WM, WN, KS, D;
+    float eff;   // MFMA-issue efficiency of the wave tile, measured (fragment reuse)
+    bool small;  // <= 168 VGPRs: member of the high-occupancy kernel
+};
+static const Cfg kCfgs[NCFG] = {
+    {2, 2, 1, 1, 4, 4, 0.80f, true},  {2, 4, 1, 1, 4, 4, 0.90f, false}, {4, 2, 1, 1, 4, 4, 0.88f, false},
+    {2, 2, 1, 2, 2, 4, 0.80f, true},  {2, 2, 2, 2, 1, 4, 0.80f, true},  {4, 4, 1, 1, 4, 2, 0.92f, false},
+    {4, 4, 2, 2, 1, 2, 0.92f, false}, {1, 2, 1, 1, 4, 4, 0.62f, true},  {4, 4, 1, 2, 2, 2, 0.92f, false},
+};
+
+template <int ID>
+__device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, float* __restrict__ smem) {
+    typedef CfgT<ID> C;
+    if (d.kind == GK_NT)
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, false>(d, tm, tn, smem);
+    else if (d.kind == GK_NN)
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, true>(d, tm, tn, smem);
+    else
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, true, true>(d, tm, tn, smem);
+}
+
+// One launch = a group of problems with up to TWO configs: the long-k wgrad problems (TN) run C0 (small
+// tiles, deep k split), everything else runs C1 (wide tiles): workgroups of both shapes share the
+// machine and fill each other's bubbles.  (One kernel holding all nine configs made hipcc park the
+// fragment arrays in scratch; pairs compile clean.)
+template <int C0, int C1>
 __global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
@@ -294,123 +345,135 @@ __global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batc
     const GemmDesc& d = batch.d[di];
     const int lt = tile - d.tile_begin;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    if (d.kind == GK_NT)
-        gemm_tile<TM, TN, WM, WN, KS, D, false, false>(d, tm, tn, smem);
-    else if (d.kind == GK_NN)
-        gemm_tile<TM, TN, WM, WN, KS, D, false, true>(d, tm, tn, smem);
+    if (C0 == C1 || d.cfg == C0)
+        run_cfg<C0>(d, tm, tn, smem);
     else
-        gemm_tile<TM, TN, WM, WN, KS, D, true, true>(d, tm, tn, smem);
+        run_cfg<C1>(d, tm, tn, smem);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-struct Cfg {
-    int TM, TN, WM, WN, KS, D;
-    float eff;  // measured MFMA-issue efficiency of the wave tile (fragment reuse)
-};
-// index + 1 = config id (what psvae_gemm_f32's `tile` / psvae_debug_force_tile select)
-static const Cfg kCfgs[] = {
-    {2, 2, 1, 1, 4, 4, 0.80f},  // 1: 32x32  tile, k split 4
-    {2, 4, 1, 1, 4, 4, 0.90f},  // 2: 32x64  tile, k split 4
-    {4, 2, 1, 1, 4, 4, 0.90f},  // 3: 64x32  tile, k split 4
-    {2, 2, 1, 2, 2, 4, 0.80f},  // 4: 32x64  tile, k split 2
-    {2, 2, 2, 2, 1, 4, 0.80f},  // 5: 64x64  tile, no split
-    {4, 4, 1, 1, 4, 2, 0.95f},  // 6: 64x64  tile, k split 4
-    {4, 4, 2, 2, 1, 2, 0.95f},  // 7: 128x128 tile, no split (large batches)
-    {1, 2, 1, 1, 4, 4, 0.60f},  // 8: 16x32  tile, k split 4 (tiny outputs)
-    {4, 4, 1, 2, 2, 2, 0.95f},  // 9: 64x128 tile, k split 2
-};
-constexpr int NCFG = sizeof(kCfgs) / sizeof(kCfgs[0]);
-
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 static int g_forced = -1;  // -1: read PSVAE_TILE once; the tuning hook psvae_debug_force_tile overrides
 void debug_force_tile(int cfg) { g_forced = cfg; }
-void debug_set_flags(int) {}
+int num_gemm_configs() { return NCFG; }
 
-// Cost model (cycles): each workgroup occupies all 4 SIMDs of a CU; per-wave MFMA cycles =
-// blocks * ksteps * 32 / eff; a launch lasts about max(longest workgroup, per-CU share).
-static double estimate(const GemmBatch& b, const Cfg& c) {
+// Cost model (cycles), fitted to rocprofv3 sweeps and tools/gemm_bench.py: a workgroup occupies the 4
+// SIMDs of a CU; per-wave MFMA cycles = chunks * 4 * blocks * 32 / eff; chunks outside whole groups
+// of D run without load/MFMA overlap (x1.6); with `slots` CUs for this problem the time is about
+// max(one workgroup, per-CU share quantised to whole rounds).
+static double estimate(const GemmDesc& d, const Cfg& c, double slots) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
-    double total = 0, longest = 0;
-    long tiles = 0;
-    for (int i = 0; i < b.n; ++i) {
-        const GemmDesc& d = b.d[i];
-        const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-        const int chunks = (d.K + 15) / 16;
-        const int per = ((chunks + c.KS - 1) / c.KS + c.D - 1) / c.D * c.D;  // padded to whole groups
-        const double cyc = per * 4.0 * c.TM * c.TN * 32.0 / c.eff + 2500.0;    // + prologue/epilogue
-        total += t * cyc;
-        longest = cyc > longest ? cyc : longest;
-        tiles += t;
-    }
-    const double rounds = (double)((tiles + 255) / 256);
-    const double share = total / 256.0 * (rounds * 256.0 / (double)tiles);  // quantisation of the last round
-    return share > longest ? share : longest;
+    const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    const int chunks = (d.K + 15) / 16;
+    const int per = (chunks + c.KS - 1) / c.KS;
+    const int full = per / c.D * c.D, rem = per - full;
+    double per_chunk = 4.0 * c.TM * c.TN * 32.0 / c.eff;
+    if (d.kind == GK_NT) per_chunk *= 1.25;  // both operands k-contiguous: half-used 128-B lines per load
+    const double cyc = full * per_chunk + rem * per_chunk * 1.6 + 2200.0 + 150.0 * c.KS;
+    if (slots < 1.0) slots = 1.0;
+    const double rounds = ceil((double)t / slots);
+    const double share = cyc * rounds;
+    return share > cyc ? share : cyc;
 }
 
-int pick_tile(const GemmBatch& b) {
-    if (g_forced < 0) g_forced = env_int("PSVAE_TILE", 0);
-    if (g_forced > 0 && g_forced <= NCFG) return g_forced;
-    int best = 1;
-    double bc = 1e30;
-    for (int i = 0; i < NCFG; ++i) {
-        const double e = estimate(b, kCfgs[i]);
-        if (e < bc) { bc = e; best = i + 1; }
-    }
-    return best;
+int pick_tile(const GemmBatch& b) {  // config of the first problem (test hook semantics)
+    GemmBatch c = b;
+    finalize_batch(c, 0);
+    return c.d[0].cfg;
 }
 
+static const int kTnCands[] = {1, 8};              // wgrad: small tiles, k split 4
+static const int kOtherCands[] = {1, 2, 4, 6, 8};  // forward / dgrad
+
+// cfg == 0: choose one config for the TN problems and one for the others; else force `cfg` everywhere
 void finalize_batch(GemmBatch& b, int cfg) {
-    const Cfg& c = kCfgs[cfg - 1];
-    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+    if (g_forced < 0) g_forced = env_int("PSVAE_TILE", 0);
+    if (cfg == 0 && g_forced > 0 && g_forced <= NCFG) cfg = g_forced;
+    double flops[MAX_GROUP], tot = 0;
+    for (int i = 0; i < b.n; ++i) {
+        flops[i] = (double)b.d[i].M * b.d[i].N * b.d[i].K;
+        tot += flops[i];
+    }
+    int pick_tn = cfg, pick_other = cfg;
+    if (cfg == 0) {
+        // each class gets its FLOP share of the 256 CUs (at least 32: small problems ride in the
+        // others' tails); within a class the slowest problem decides
+        for (int cls = 0; cls < 2; ++cls) {
+            const int* cands = cls ? kOtherCands : kTnCands;
+            const int ncand = cls ? 5 : 2;
+            double best = 1e30;
+            int pick = cands[0];
+            for (int k = 0; k < ncand; ++k) {
+                double worst = 0;
+                for (int i = 0; i < b.n; ++i) {
+                    if ((b.d[i].kind == GK_TN) != (cls == 0)) continue;
+                    double slots = 256.0 * flops[i] / tot;
+                    if (slots < 32.0) slots = 32.0;
+                    const double e = estimate(b.d[i], kCfgs[cands[k] - 1], slots);
+                    worst = e > worst ? e : worst;
+                }
+                if (worst < best) { best = worst; pick = cands[k]; }
+            }
+            (cls ? pick_other : pick_tn) = pick;
+        }
+    }
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
-        b.d[i].tiles_m = (b.d[i].M + BM - 1) / BM;
-        b.d[i].tiles_n = (b.d[i].N + BN - 1) / BN;
-        b.d[i].tile_begin = t;
-        t += b.d[i].tiles_m * b.d[i].tiles_n;
+        GemmDesc& d = b.d[i];
+        d.cfg = d.kind == GK_TN ? pick_tn : pick_other;
+        const Cfg& c = kCfgs[d.cfg - 1];
+        const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+        d.tiles_m = (d.M + BM - 1) / BM;
+        d.tiles_n = (d.N + BN - 1) / BN;
+        d.tile_begin = t;
+        t += d.tiles_m * d.tiles_n;
     }
     b.total_tiles = t;
     b.dbg = 0;
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D>
-static hipError_t launch_cfg(const GemmBatch& b, hipStream_t stream) {
-    constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
-    constexpr size_t lds = (size_t)(KS * BM * (BN + 4) + KS * BM) * sizeof(float);
+static size_t lds_bytes(const Cfg& c) {
+    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM) * sizeof(float);
+}
+
+template <int C0, int C1>
+static hipError_t launch_pair(const GemmBatch& b, size_t lds, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<TM, TN, WM, WN, KS, D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_kernel<TM, TN, WM, WN, KS, D>), dim3(b.total_tiles), dim3(NTHR), lds, stream, b);
+    hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1>), dim3(b.total_tiles), dim3(NTHR), lds, stream, b);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
-    if (cfg == 0) cfg = pick_tile(b);
-    if (cfg < 1 || cfg > NCFG) return hipErrorInvalidValue;
+    if (cfg < 0 || cfg > NCFG) return hipErrorInvalidValue;
     finalize_batch(b, cfg);
     if (b.total_tiles == 0) return hipSuccess;
-    switch (cfg) {
-        case 1: return launch_cfg<2, 2, 1, 1, 4, 4>(b, stream);
-        case 2: return launch_cfg<2, 4, 1, 1, 4, 4>(b, stream);
-        case 3: return launch_cfg<4, 2, 1, 1, 4, 4>(b, stream);
-        case 4: return launch_cfg<2, 2, 1, 2, 2, 4>(b, stream);
-        case 5: return launch_cfg<2, 2, 2, 2, 1, 4>(b, stream);
-        case 6: return launch_cfg<4, 4, 1, 1, 4, 2>(b, stream);
-        case 7: return launch_cfg<4, 4, 2, 2, 1, 2>(b, stream);
-        case 8: return launch_cfg<1, 2, 1, 1, 4, 4>(b, stream);
-        case 9: return launch_cfg<4, 4, 1, 2, 2, 2>(b, stream);
-        default: return hipErrorInvalidValue;
+    int c0 = 0, c1 = 0;  // c0: config of the TN problems, c1: of the others (equal if a class is absent)
+    size_t lds = 0;
+    for (int i = 0; i < b.n; ++i) {
+        (b.d[i].kind == GK_TN ? c0 : c1) = b.d[i].cfg;
+        const size_t l = lds_bytes(kCfgs[b.d[i].cfg - 1]);
+        lds = l > lds ? l : lds;
     }
+    if (c0 == 0) c0 = c1;
+    if (c1 == 0) c1 = c0;
+#define PSVAE_PAIR(A, B) if (c0 == A && c1 == B) return launch_pair<A, B>(b, lds, stream)
+    PSVAE_PAIR(1, 1); PSVAE_PAIR(2, 2); PSVAE_PAIR(3, 3); PSVAE_PAIR(4, 4); PSVAE_PAIR(5, 5);
+    PSVAE_PAIR(6, 6); PSVAE_PAIR(7, 7); PSVAE_PAIR(8, 8); PSVAE_PAIR(9, 9);
+    PSVAE_PAIR(1, 2); PSVAE_PAIR(1, 4); PSVAE_PAIR(1, 6); PSVAE_PAIR(1, 8);
+    PSVAE_PAIR(8, 1); PSVAE_PAIR(8, 2); PSVAE_PAIR(8, 4); PSVAE_PAIR(8, 6);
+#undef PSVAE_PAIR
+    return hipErrorInvalidValue;
 }
-
-int num_gemm_configs() { return NCFG; }
 
 }  // namespace psvae

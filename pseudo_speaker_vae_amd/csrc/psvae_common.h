@@ -35,6 +35,7 @@ struct GemmDesc {
     int M, N, K;
     int lda, ldb, ldc;
     int kind, epi;
+    int cfg;  // GEMM config id of this problem (set by finalize_batch)
     int tiles_m, tiles_n;
     int tile_begin;  // first linear tile of this problem inside the launch
 };

@@ -159,7 +159,9 @@ void run(const char* name, int M, int N, int K, float* dA, float* dB, float* dC)
            usc, 2.0 * M * N * K / (usc * 1e-6) / 1e12, maxerr);
 }
 
-int main() {
+extern "C" int conc_main();
+int main(int argc, char** argv) {
+    if (argc > 1) return conc_main();
     const int MAXE = 1024 * 1024;
     const int NS = 17;
     hA.resize(MAXE); hB.resize(MAXE);
@@ -199,11 +201,91 @@ int main() {
     run<2, 2, 1, 1, 4, 4, true, true>("TT t22 w1x1 ks4 D4", 1024, 512, 512, dA, dB, dC);
     run<4, 4, 1, 1, 4, 4, true, true>("TT t44 w1x1 ks4 D4", 1024, 512, 512, dA, dB, dC);
     run<4, 2, 1, 1, 4, 4, true, true>("TT t42 w1x1 ks4 D4", 1024, 512, 512, dA, dB, dC);
+    printf("--- backward stage B1 pieces: TN 256x512x1024 (wgrad) and NN 1024x512x256 (dgrad)\n");
+    run<2, 2, 1, 1, 4, 4, true, true>("TN t22 w1x1 ks4 D4", 256, 512, 1024, dA, dB, dC);
+    run<1, 2, 1, 1, 4, 4, true, true>("TN t12 w1x1 ks4 D4", 256, 512, 1024, dA, dB, dC);
+    run<2, 4, 1, 1, 4, 4, true, true>("TN t24 w1x1 ks4 D4", 256, 512, 1024, dA, dB, dC);
+    run<2, 2, 1, 1, 4, 4, false, true>("NN t22 w1x1 ks4 D4", 1024, 512, 256, dA, dB, dC);
+    run<2, 4, 1, 1, 4, 4, false, true>("NN t24 w1x1 ks4 D4", 1024, 512, 256, dA, dB, dC);
+    run<2, 2, 1, 2, 2, 4, false, true>("NN t22 w1x2 ks2 D4", 1024, 512, 256, dA, dB, dC);
+    run<2, 2, 2, 2, 1, 4, false, true>("NN t22 w2x2 ks1 D4", 1024, 512, 256, dA, dB, dC);
+    printf("--- B3 pieces: TN 512x64x1024, NN 1024x64x512;  B4 pieces: TN 64x512x1024, NN 1024x512x64\n");
+    run<2, 2, 1, 1, 4, 4, true, true>("TN t22 w1x1 ks4 D4", 512, 64, 1024, dA, dB, dC);
+    run<1, 2, 1, 1, 4, 4, true, true>("TN t12 w1x1 ks4 D4", 512, 64, 1024, dA, dB, dC);
+    run<2, 2, 1, 1, 4, 4, false, true>("NN t22 w1x1 ks4 D4", 1024, 64, 512, dA, dB, dC);
+    run<1, 2, 1, 1, 4, 4, false, true>("NN t12 w1x1 ks4 D4", 1024, 64, 512, dA, dB, dC);
+    run<2, 2, 1, 1, 4, 4, true, true>("TN t22 w1x1 ks4 D4", 64, 512, 1024, dA, dB, dC);
+    run<1, 2, 1, 1, 4, 4, true, true>("TN t12 w1x1 ks4 D4", 64, 512, 1024, dA, dB, dC);
+    run<2, 2, 2, 2, 1, 4, false, true>("NN t22 w2x2 ks1 D4", 1024, 512, 64, dA, dB, dC);
     printf("--- skinny: mu/logvar heads NT 1024x64x512, dec1 NT 1024x512x64\n");
     run<2, 2, 1, 1, 4, 4, false, false>("NT t22 w1x1 ks4 D4", 1024, 64, 512, dA, dB, dC);
     run<1, 2, 1, 1, 4, 4, false, false>("NT t12 w1x1 ks4 D4", 1024, 64, 512, dA, dB, dC);
     run<1, 4, 1, 1, 4, 4, false, false>("NT t14 w1x1 ks4 D4", 1024, 64, 512, dA, dB, dC);
     run<2, 2, 2, 2, 1, 4, false, false>("NT t22 w2x2 ks1 D4", 1024, 512, 64, dA, dB, dC);
     run<1, 2, 2, 2, 1, 4, false, false>("NT t12 w2x2 ks1 D4", 1024, 512, 64, dA, dB, dC);
+    return 0;
+}
+
+// ---- concurrency experiment: a dgrad-like chain and a wgrad-like chain, one stream vs two ----------
+extern "C" int conc_main() {
+    const int MAXE = 1024 * 1024;
+    float *dA, *dB, *dC1, *dC2;
+    hipMalloc(&dA, MAXE * 4 * 2); hipMalloc(&dB, MAXE * 4 * 2); hipMalloc(&dC1, MAXE * 4); hipMalloc(&dC2, MAXE * 4);
+    hipMemset(dA, 0, MAXE * 8); hipMemset(dB, 0, MAXE * 8);
+    auto kd = rd_gemm<2, 4, 1, 1, 4, 4, false, true>;   // NN 1024x512x512, 256 WGs
+    auto kw = rd_gemm<2, 2, 1, 1, 4, 4, true, true>;    // TN 512x512x1024, 256 WGs
+    const size_t ld_ = 4 * 32 * 68 * 4, lw_ = 4 * 32 * 36 * 4;
+    hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld_);
+    hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_);
+    hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+    hipEvent_t e0, e1, ev[16], ej; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&ej);
+    for (auto& e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    const int NCH = 6, REP = 20;
+    float ms;
+    // (a) one stream, alternating d and w
+    for (int it = 0; it < 2; ++it) {
+        hipEventRecord(e0, s1);
+        for (int r = 0; r < REP; ++r)
+            for (int i = 0; i < NCH; ++i) {
+                hipLaunchKernelGGL(kd, dim3(256), dim3(256), ld_, s1, dA, dB, dC1, 1024, 512, 512, 512, 512, 512);
+                hipLaunchKernelGGL(kw, dim3(256), dim3(256), lw_, s1, dA + MAXE, dB + MAXE, dC2, 512, 512, 1024, 512, 512, 512);
+            }
+        hipEventRecord(e1, s1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("one stream  : %.2f us per (dgrad+wgrad) pair\n", ms * 1e3 / (REP * NCH));
+    // (b) two streams: d chain on s1; w_i on s2 waits for d_i
+    for (int it = 0; it < 2; ++it) {
+        hipEventRecord(e0, s1);
+        hipStreamWaitEvent(s2, e0, 0);
+        for (int r = 0; r < REP; ++r)
+            for (int i = 0; i < NCH; ++i) {
+                hipLaunchKernelGGL(kd, dim3(256), dim3(256), ld_, s1, dA, dB, dC1, 1024, 512, 512, 512, 512, 512);
+                hipEventRecord(ev[i], s1);
+                hipStreamWaitEvent(s2, ev[i], 0);
+                hipLaunchKernelGGL(kw, dim3(256), dim3(256), lw_, s2, dA + MAXE, dB + MAXE, dC2, 512, 512, 1024, 512, 512, 512);
+            }
+        hipEventRecord(ej, s2); hipStreamWaitEvent(s1, ej, 0);
+        hipEventRecord(e1, s1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("two streams : %.2f us per (dgrad+wgrad) pair\n", ms * 1e3 / (REP * NCH));
+    // (c) same two-stream structure captured in one hipGraph
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(s1, hipStreamCaptureModeGlobal);
+    hipEventRecord(ev[15], s1); hipStreamWaitEvent(s2, ev[15], 0);
+    for (int i = 0; i < NCH; ++i) {
+        hipLaunchKernelGGL(kd, dim3(256), dim3(256), ld_, s1, dA, dB, dC1, 1024, 512, 512, 512, 512, 512);
+        hipEventRecord(ev[i], s1);
+        hipStreamWaitEvent(s2, ev[i], 0);
+        hipLaunchKernelGGL(kw, dim3(256), dim3(256), lw_, s2, dA + MAXE, dB + MAXE, dC2, 512, 512, 1024, 512, 512, 512);
+    }
+    hipEventRecord(ej, s2); hipStreamWaitEvent(s1, ej, 0);
+    hipStreamEndCapture(s1, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    for (int it = 0; it < 2; ++it) {
+        hipEventRecord(e0, s1);
+        for (int r = 0; r < REP; ++r) hipGraphLaunch(ge, s1);
+        hipEventRecord(e1, s1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("graph 2-br  : %.2f us per (dgrad+wgrad) pair\n", ms * 1e3 / (REP * NCH));
     return 0;
 }
