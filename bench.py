@@ -138,6 +138,10 @@ def main():
     loss = eng.loss3.detach().cpu().tolist()
 
     if rank == 0:
+        traffic = None  # L2-fill bytes per step from the committed PMC passes (profiles/, cfg2 shape only)
+        pmc = os.path.join(REPO, "profiles", "r01_cfg2_pmc.json")
+        if (D, Z, B) == (256, 64, 1024) and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_step"]
         fpe = flop_per_embedding(D, Z)
         step_s_dev = dev_ms / 1e3 / args.steps
         achieved = fpe * B / step_s_dev / 1e12  # per GPU, over the HIP-event duration of the step
@@ -154,7 +158,7 @@ def main():
                                    f"batch={B}/GPU, global_batch={B * world}, fp32",
                        "launch": mode, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5)},
             "loss": [round(v, 6) for v in loss],
         }
