@@ -127,6 +127,17 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
                        const psvae_grads* grads, float* g_x, void* scratch, uint32_t flags,
                        uint32_t phases, void* stream);
 
+/* One whole training pass = psvae_forward_f32 + psvae_elbo_f32 + psvae_backward_f32(elbo=1) for the
+ * default loss (MSE/10 + beta*KL, no decoder normalisation), as ONE launch sequence with the elementwise
+ * work folded into GEMM epilogues (14 launches instead of 19).  What a Lightning step does between
+ * lightning.py:67 and the end of loss.backward().  phases: PSVAE_PHASE_DECODER = forward + decoder
+ * backward (decoder gradients and loss3 complete), PSVAE_PHASE_ENCODER = encoder backward. */
+int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
+                         const float* eps_in /* nullable */, uint64_t seed, uint64_t offset,
+                         uint64_t* rng_state /* nullable */, const psvae_acts* acts, float* x_hat, float* mu,
+                         float* logvar, float beta, const float* grad_loss /* nullable = 1 */,
+                         const psvae_grads* grads, float* loss3, void* scratch, uint32_t phases, void* stream);
+
 /* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
  * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
 size_t psvae_decode_scratch_bytes(int64_t N);

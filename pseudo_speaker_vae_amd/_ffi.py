@@ -25,7 +25,8 @@ ABI_VERSION = 1
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
     "psvae_version", "psvae_debug_force_tile", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
-    "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_decode_scratch_bytes",
+    "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
+    "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32",
 )
 
@@ -84,11 +85,14 @@ def lib() -> C.CDLL:
     L.psvae_elbo_f32.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, f32, vp, vp, u32, vp]
     L.psvae_backward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), C.POINTER(Acts),
                                      vp, vp, vp, vp, vp, vp, C.c_int, f32, vp, C.POINTER(Grads), vp, vp, u32, u32, vp]
+    L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
+                                       vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_decode_f32.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp, u32, vp]
     L.psvae_gemm_f32.argtypes = [C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp, vp, C.c_int, C.c_int, vp]
     f64 = C.c_double
     L.psvae_adam_step_f32.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64, f64, vp]
     for fn in ("psvae_philox_normal_f32", "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32",
+               "psvae_train_step_f32", "psvae_debug_force_tile",
                "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32"):
         getattr(L, fn).restype = C.c_int
     if L.psvae_version() != ABI_VERSION:

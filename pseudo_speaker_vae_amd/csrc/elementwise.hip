@@ -67,6 +67,71 @@ hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t o
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// fixed-order sum over the 256 threads of a block; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* sh4) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// fused-step reparameterisation: z = mu + exp(0.5 lv) * eps, plus one KL partial per block
+//   kl_partials[blk] = sum over the block's elements of (1 + lv - mu^2 - e^lv)   (lightning.py:115-117)
+// grid is FIXED to reparam_blocks(n) (each block owns a contiguous slice) so the sum order is fixed.
+constexpr int REPARAM_ELEMS_PER_BLOCK = 1024;  // 256 lanes x one Philox block of 4
+int reparam_blocks(int64_t n) { return (int)((n + REPARAM_ELEMS_PER_BLOCK - 1) / REPARAM_ELEMS_PER_BLOCK); }
+
+__global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                         const float* __restrict__ eps_in,
+                                                         const uint64_t* __restrict__ rng, uint64_t seed,
+                                                         uint64_t offset, float* __restrict__ eps_out,
+                                                         float* __restrict__ z, float* __restrict__ kl_partials,
+                                                         int64_t n, int vec_ok) {
+    __shared__ float sh4[4];
+    if (rng) { seed = rng[0]; offset = rng[1]; }
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = 4 * b;
+    float kl = 0.f;
+    if (e < n) {
+        if (vec_ok && e + 3 < n) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mu + e);
+            const f32x4 l = *reinterpret_cast<const f32x4*>(lv + e);
+            const f32x4 ep = eps_in ? *reinterpret_cast<const f32x4*>(eps_in + e) : philox_normal4(offset + (uint64_t)b, seed);
+            f32x4 zz;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                zz[i] = m[i] + expf(0.5f * l[i]) * ep[i];
+                kl += 1.0f + l[i] - m[i] * m[i] - expf(l[i]);
+            }
+            *reinterpret_cast<f32x4*>(eps_out + e) = ep;
+            *reinterpret_cast<f32x4*>(z + e) = zz;
+        } else {
+            f32x4 ep = {0.f, 0.f, 0.f, 0.f};
+            if (!eps_in) ep = philox_normal4(offset + (uint64_t)b, seed);
+            for (int i = 0; i < 4; ++i) {
+                if (e + i < n) {
+                    const float ee = eps_in ? eps_in[e + i] : ep[i];
+                    const float m = mu[e + i], l = lv[e + i];
+                    eps_out[e + i] = ee;
+                    z[e + i] = m + expf(0.5f * l) * ee;
+                    kl += 1.0f + l - m * m - expf(l);
+                }
+            }
+        }
+    }
+    const float s = block_sum_256(kl, sh4);
+    if (threadIdx.x == 0) kl_partials[blockIdx.x] = s;
+}
+
 // z = mu + exp(0.5 lv) * eps     (model.py:56-57)
 __global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
                                                       const float* __restrict__ eps_in, uint64_t seed, uint64_t offset,
@@ -114,14 +179,6 @@ hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in,
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// wave helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // row L2 normalisation (model.py:60-61): one wavefront per row
@@ -304,6 +361,59 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
         g_mu[i] = gm;
         g_lv[i] = gl;
     }
+}
+
+// fused-step variant: elementwise part as above (ELBO gradient always on); block 0 then finishes the
+// loss from the partial sums and advances the Philox state (every reader of rng[1] ran launches ago)
+__global__ __launch_bounds__(256) void reparam_bwd_final_kernel(
+    const float* __restrict__ g_z, const float* __restrict__ mu, const float* __restrict__ lv,
+    const float* __restrict__ eps, float beta, const float* __restrict__ go_p, float* __restrict__ g_mu,
+    float* __restrict__ g_lv, int64_t n, int B, int D, const float* __restrict__ kl_partials, int n_kl,
+    const float* __restrict__ recon_partials, int n_recon, float* __restrict__ loss3, uint64_t* rng, uint64_t nblk) {
+    __shared__ float sh4[4];
+    const float go = go_p ? *go_p : 1.0f;
+    const float kb = go * beta / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gz = g_z[i], l = lv[i];
+        g_mu[i] = gz + kb * mu[i];
+        g_lv[i] = gz * eps[i] * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
+    }
+    if (blockIdx.x == 0) {
+        float k = 0.f, r = 0.f;
+        for (int i = threadIdx.x; i < n_kl; i += 256) k += kl_partials[i];
+        for (int i = threadIdx.x; i < n_recon; i += 256) r += recon_partials[i];
+        const float ks = block_sum_256(k, sh4);
+        __syncthreads();
+        const float rs = block_sum_256(r, sh4);
+        if (threadIdx.x == 0) {
+            const float recon = rs / ((float)B * (float)D) / 10.0f;
+            const float kl = -0.5f * ks / (float)B;
+            loss3[0] = recon + beta * kl;
+            loss3[1] = recon;
+            loss3[2] = kl;
+            if (rng) rng[1] += nblk;
+        }
+    }
+}
+
+hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng, uint64_t seed,
+                             uint64_t offset, float* eps_out, float* z, float* kl_partials, int64_t n, hipStream_t s) {
+    const int vec_ok = al16(mu) && al16(lv) && al16(eps_out) && al16(z) && (!eps_in || al16(eps_in));
+    if (eps_in) rng = nullptr;
+    hipLaunchKernelGGL(reparam_kl_kernel, dim3(reparam_blocks(n)), dim3(256), 0, s, mu, lv, eps_in, rng, seed, offset,
+                       eps_out, z, kl_partials, n, vec_ok);
+    return hipGetLastError();
+}
+
+hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps, float beta,
+                                    const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
+                                    const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
+                                    float* loss3, uint64_t* rng, hipStream_t s) {
+    const int64_t n = (int64_t)B * Z;
+    hipLaunchKernelGGL(reparam_bwd_final_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g_z, mu, lv, eps, beta, go,
+                       g_mu, g_lv, n, B, D, kl_partials, n_kl, recon_partials, n_recon, loss3, rng,
+                       (uint64_t)((n + 3) / 4));
+    return hipGetLastError();
 }
 
 hipError_t launch_reparam_bwd(const float* g_z, const float* mu, const float* lv, const float* eps,

@@ -233,7 +233,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     const int c4 = tid % CQ, r0 = tid / CQ;
     const int col = n0 + 4 * c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) {
+    float sq = 0.f;  // EPI_BIAS_RECON: this thread's share of sum (x_hat - x)^2
+    const float gsc = (epi == EPI_BIAS_RECON) ? d.scale * (d.go ? ldg<float>(d.go) : 1.0f) : 0.f;
+    if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_RECON) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (col + e < N) bias4[e] = ldg<float>(aux + col + e);
@@ -264,6 +266,30 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+        } else if (epi == EPI_BIAS_RECON) {
+            v += bias4;
+            f32x4 xt = {0.f, 0.f, 0.f, 0.f};
+            if (full) {
+                xt = ldg<f32x4>(d.aux2 + o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) xt[e] = ldg<float>(d.aux2 + o + e);
+            }
+            f32x4 gy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float df = (col + e < N) ? v[e] - xt[e] : 0.f;
+                sq += df * df;
+                gy[e] = gsc * df;
+            }
+            if (full) {
+                stg<f32x4>(d.C2 + o, gy);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) stg<float>(d.C2 + o + e, gy[e]);
+            }
         } else if (epi == EPI_MASK || epi == EPI_ACCUM) {
             const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
@@ -284,6 +310,14 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
             for (int e = 0; e < 4; ++e)
                 if (col + e < N) stg<float>(C + o + e, v[e]);
         }
+    }
+    if (epi == EPI_BIAS_RECON) {  // fixed-order block sum of the squared errors -> one partial per tile
+        float* __restrict__ red = smem + KS * (BM * SC) + KS * BM;  // 4 floats past the csum area
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sq += __shfl_xor(sq, o2);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) stg<float>(d.partials + tm * d.tiles_n + tn, (red[0] + red[1]) + (red[2] + red[3]));
     }
     if (AKM && d.colsum != nullptr && tn == 0 && tid < BM) {
         float s = csum_s[tid];
@@ -437,7 +471,7 @@ void finalize_batch(GemmBatch& b, int cfg) {
 
 static size_t lds_bytes(const Cfg& c) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
-    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM) * sizeof(float);
+    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 4) * sizeof(float);
 }
 
 template <int C0, int C1>

@@ -21,7 +21,8 @@ int check_dims(const psvae_dims* d) {
 
 // scratch carve (floats), identical for every call so phases can share it
 struct Scratch {
-    float *y, *gy, *dd2, *dd1, *gz, *gmu, *glv, *dh2m, *dh2s, *dh1m, *dh1s, *partials;
+    float *y, *gy, *dd2, *dd1, *gz, *gmu, *glv, *dh2m, *dh2s, *dh1m, *dh1s, *partials, *kl_partials, *recon_partials;
+    int n_recon_max;
     size_t bytes;
 };
 
@@ -45,6 +46,9 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
     s.dh1m = take((size_t)B * H);
     s.dh1s = take((size_t)B * H);
     s.partials = take(2 * 1024);
+    s.kl_partials = take((size_t)reparam_blocks(B * Z));
+    s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));  // smallest GEMM tile is 16 x 32
+    s.recon_partials = take((size_t)s.n_recon_max);
     s.bytes = off;
     return s;
 }
@@ -278,6 +282,122 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             GemmBatch b2{};
             add(b2, make_desc(GK_NN, B, D, H, sc.dh1s, H, P[6], D, g_x, D, EPI_ACCUM, nullptr));
             RET_IF(launch_gemm_batch(b2, 0, s));
+        }
+    }
+    return 0;
+}
+
+// forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs:
+//   reparam also emits KL partial sums; the last decoder GEMM's epilogue also writes the MSE gradient and
+//   MSE partial sums; the reparam-backward kernel also finishes the loss and advances the Philox state.
+// 14 launches instead of 19.  Only for the default loss (MSE/10, no decoder normalisation).
+int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const float* eps_in,
+                         uint64_t seed, uint64_t offset, uint64_t* rng_state, const psvae_acts* acts, float* x_hat,
+                         float* mu, float* logvar, float beta, const float* grad_loss, const psvae_grads* grads,
+                         float* loss3, void* scratch, uint32_t phases, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!x || !params || !acts || !x_hat || !mu || !logvar || !grads || !loss3 || !scratch) return PSVAE_ERR_NULL;
+    if (phases == 0 || (phases & ~PSVAE_PHASE_ALL)) return PSVAE_ERR_ARG;
+    for (int i = 0; i < PSVAE_NPARAM; ++i)
+        if (!params->p[i] || !grads->g[i]) return PSVAE_ERR_NULL;
+    if (!acts->h1m || !acts->h2m || !acts->h1s || !acts->h2s || !acts->eps || !acts->z || !acts->d1 || !acts->d2)
+        return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* P = params->p;
+    float* const* G = grads->g;
+    Scratch sc = carve(scratch, B, D, Z);
+    const int n_kl = reparam_blocks((int64_t)B * Z);
+
+    if (phases & PSVAE_PHASE_DECODER) {
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, B, H, D, x, D, P[0], D, acts->h1m, H, EPI_BIAS_RELU, P[1]));
+            add(b, make_desc(GK_NT, B, H, D, x, D, P[6], D, acts->h1s, H, EPI_BIAS_RELU, P[7]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, B, H, H, acts->h1m, H, P[2], H, acts->h2m, H, EPI_BIAS_RELU, P[3]));
+            add(b, make_desc(GK_NT, B, H, H, acts->h1s, H, P[8], H, acts->h2s, H, EPI_BIAS_RELU, P[9]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, B, Z, H, acts->h2m, H, P[4], H, mu, Z, EPI_BIAS, P[5]));
+            add(b, make_desc(GK_NT, B, Z, H, acts->h2s, H, P[10], H, logvar, Z, EPI_BIAS, P[11]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
+                                 (int64_t)B * Z, s));
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, B, H, Z, acts->z, Z, P[12], Z, acts->d1, H, EPI_BIAS_RELU, P[13]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_NT, B, H, H, acts->d1, H, P[14], H, acts->d2, H, EPI_BIAS_RELU, P[15]));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        int n_recon = 0;
+        {  // decoder output + MSE gradient + MSE partial sums in one epilogue (lightning.py:113)
+            GemmBatch b{};
+            GemmDesc d = make_desc(GK_NT, B, D, H, acts->d2, H, P[16], H, x_hat, D, EPI_BIAS_RECON, P[17]);
+            d.aux2 = x;
+            d.C2 = sc.gy;
+            d.go = grad_loss;
+            d.scale = 2.0f / (10.0f * (float)B * (float)D);
+            d.partials = sc.recon_partials;
+            add(b, d);
+            RET_IF(launch_gemm_batch(b, 0, s));
+            n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
+            if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, D, H, B, sc.gy, D, acts->d2, H, G[16], H, EPI_NONE, nullptr, G[17]));
+            add(b, make_desc(GK_NN, B, H, D, sc.gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, H, B, sc.dd2, H, acts->d1, H, G[14], H, EPI_NONE, nullptr, G[15]));
+            add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, Z, B, sc.dd1, H, acts->z, Z, G[12], Z, EPI_NONE, nullptr, G[13]));
+            add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, acts->eps, beta, grad_loss, sc.gmu, sc.glv, B, Z, D,
+                                        sc.kl_partials, n_kl, sc.recon_partials, n_recon, loss3,
+                                        eps_in ? nullptr : rng_state, s));
+    }
+    if (phases & PSVAE_PHASE_ENCODER) {
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, Z, H, B, sc.gmu, Z, acts->h2m, H, G[4], H, EPI_NONE, nullptr, G[5]));
+            add(b, make_desc(GK_TN, Z, H, B, sc.glv, Z, acts->h2s, H, G[10], H, EPI_NONE, nullptr, G[11]));
+            add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
+            add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, H, B, sc.dh2m, H, acts->h1m, H, G[2], H, EPI_NONE, nullptr, G[3]));
+            add(b, make_desc(GK_TN, H, H, B, sc.dh2s, H, acts->h1s, H, G[8], H, EPI_NONE, nullptr, G[9]));
+            add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
+            add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
+            RET_IF(launch_gemm_batch(b, 0, s));
+        }
+        {
+            GemmBatch b{};
+            add(b, make_desc(GK_TN, H, D, B, sc.dh1m, H, x, D, G[0], D, EPI_NONE, nullptr, G[1]));
+            add(b, make_desc(GK_TN, H, D, B, sc.dh1s, H, x, D, G[6], D, EPI_NONE, nullptr, G[7]));
+            RET_IF(launch_gemm_batch(b, 0, s));
         }
     }
     return 0;

@@ -21,6 +21,8 @@ enum GemmEpi {
     EPI_BIAS_RELU = 2,  // C = relu(acc + bias[col])
     EPI_MASK = 3,       // C = acc * (mask[row][col] > 0)     (ReLU backward, mask = saved activation)
     EPI_ACCUM = 4,      // C += acc                            (second dgrad into the same buffer)
+    EPI_BIAS_RECON = 5, // C = acc + bias; C2 = scale*go*(C - aux2); partials[tile] = sum (C - aux2)^2
+                        // (decoder output + MSE gradient + MSE partial sums, lightning.py:113)
 };
 
 struct GemmDesc {
@@ -32,6 +34,11 @@ struct GemmDesc {
     const float* ctab;     // nullable: conditional table [6,N] added per row in EPI_BIAS* (cfg3)
     const int32_t* gender; // [rows] labels for ctab
     const int32_t* age;
+    const float* aux2;     // EPI_BIAS_RECON: the target x[M,ldc]
+    float* C2;             // EPI_BIAS_RECON: gradient output g_y[M,ldc]
+    const float* go;       // EPI_BIAS_RECON: device scalar multiplying the gradient (nullable = 1)
+    float* partials;       // EPI_BIAS_RECON: one partial sum per workgroup tile of this problem
+    float scale;
     int M, N, K;
     int lda, ldb, ldc;
     int kind, epi;
@@ -61,6 +68,7 @@ inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda
     GemmDesc d{};
     d.A = A; d.B = B; d.C = C; d.aux = aux; d.colsum = colsum;
     d.ctab = nullptr; d.gender = nullptr; d.age = nullptr;
+    d.aux2 = nullptr; d.C2 = nullptr; d.go = nullptr; d.partials = nullptr; d.scale = 1.f;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.kind = kind; d.epi = epi;
     return d;
 }
@@ -71,6 +79,12 @@ hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t o
 // rng (nullable, device {seed, offset}) overrides seed/offset and is advanced by ceil(n/4) afterwards
 hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in, uint64_t seed,
                           uint64_t offset, uint64_t* rng, float* eps_out, float* z, int64_t n, hipStream_t s);
+// fused-step variant: also writes one KL partial sum per block (kl_partials[reparam_blocks(n)]) and
+// leaves the rng advance to launch_reparam_bwd_final
+int reparam_blocks(int64_t n);
+hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
+                             uint64_t seed, uint64_t offset, float* eps_out, float* z, float* kl_partials,
+                             int64_t n, hipStream_t s);
 // row L2 normalise: xh = y / max(||y||, 1e-12), ynorm = that max
 hipError_t launch_normalize_rows(const float* y, float* xh, float* ynorm, int B, int D, hipStream_t s);
 // loss3 = {total, recon, kl}
@@ -85,6 +99,12 @@ hipError_t launch_recon_grad(const float* x, const float* xh, const float* ynorm
 hipError_t launch_reparam_bwd(const float* g_z, const float* mu, const float* lv, const float* eps,
                               const float* g_mu_up, const float* g_lv_up, bool elbo, float beta,
                               const float* go, float* g_mu, float* g_lv, int B, int Z, hipStream_t s);
+// fused-step variant of reparam_bwd: block 0 additionally finishes the loss (fixed-order sums of the KL
+// and MSE partials -> loss3 = {total, recon, kl}) and advances the device Philox state
+hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps,
+                                    float beta, const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
+                                    const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
+                                    float* loss3, uint64_t* rng, hipStream_t s);
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);

@@ -103,6 +103,17 @@ class TrainEngine:
     def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
+        if self.flags == 0:  # default loss: the fused 14-launch sequence
+            kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
+            if self.world == 1:
+                ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
+                return
+            ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
+            self.averager.reduce_bucket(1)             # decoder grads: runs under the encoder backward
+            ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_ENCODER, **kw)
+            self.averager.reduce_bucket(0)             # encoder grads + the 3 loss scalars
+            self.averager.wait()
+            return
         xh, mu, lv = ops.vae_forward(self.ws, x, self.params, eps, 0, 0, self.flags, outs=self.outs,
                                      rng_state=self.rng_state)
         ops.elbo(self.ws, x, xh, mu, lv, self.beta, self.flags, self.loss3)

@@ -116,6 +116,20 @@ def vae_backward(ws: Workspace, x, params: Sequence[torch.Tensor], xh, mu, lv, g
     return grads
 
 
+def train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], outs, loss3,
+               beta: float = 1.0, eps: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
+               rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
+               phases: int = _ffi.PHASE_ALL):
+    """fused forward + ELBO + backward (default loss): psvae_train_step_f32"""
+    P = _ffi.make_params(params)
+    G = _ffi.make_grads(grads)
+    xh, mu, lv = outs
+    _ffi.check(_ffi.lib().psvae_train_step_f32(
+        C.byref(ws.dims), _ffi.ptr(x), C.byref(P), _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state),
+        C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv), beta, _ffi.ptr(grad_loss), C.byref(G),
+        _ffi.ptr(loss3), _ffi.ptr(ws.scratch), phases, _ffi.stream_ptr()), "train_step")
+
+
 def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
            cond_tab=None, gender=None, age=None, out: Optional[torch.Tensor] = None,
            scratch: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -212,3 +212,31 @@ def test_cond_forward_backward_matches_oracle(ops):
         assert_close(g.cpu(), ref[k], REL_TOL, "grad " + k)
     for k, g in zip(O.COND_KEYS, gtab):
         assert_close(g.cpu(), tref[k], REL_TOL, "grad " + k)
+
+
+@pytest.mark.parametrize("D,Z,B", [(256, 64, 1024), (256, 32, 64), (512, 128, 1024), (256, 64, 37), (784, 20, 32)])
+def test_fused_train_step_matches_unfused_path_and_oracle(ops, D, Z, B):
+    """psvae_train_step_f32 (elementwise work folded into GEMM epilogues) == forward + elbo + backward."""
+    p = O.init_params(D, Z, 5)
+    torch.manual_seed(D + B)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    go = 1.7
+    ref = run_step(ops, p, x, eps, 0.9, False, False, go=go)
+    ws = ops.Workspace(B, D, Z, DEV)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    grads = [torch.full_like(t, float("nan")) for t in params]
+    outs = ws.new_outputs()
+    loss3 = torch.full((3,), float("nan"), device=DEV)
+    ops.train_step(ws, x.to(DEV), params, grads, outs, loss3, beta=0.9, eps=eps.to(DEV),
+                   grad_loss=torch.tensor([go], device=DEV))
+    torch.cuda.synchronize()
+    assert_close(outs[0].cpu(), ref["x_hat"], 1e-6, "x_hat")
+    assert_close(loss3.cpu(), ref["loss3"], 1e-6, "loss3")
+    for k, g in zip(O.PARAM_KEYS, grads):
+        assert_close(g.cpu(), ref["grads"][k], 2e-6, "fused vs unfused grad " + k)
+    masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
+    losses, ograds, _, _ = O.train_step(p, x, eps, 0.9, go=go, masks=masks)
+    for i, k in enumerate(("total", "recon", "kl")):
+        assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
+    for k, g in zip(O.PARAM_KEYS, grads):
+        assert_close(g.cpu(), ograds[k], REL_TOL, "fused vs oracle grad " + k)
