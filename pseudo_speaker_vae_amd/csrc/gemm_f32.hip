@@ -372,12 +372,20 @@ __device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, float
 template <int C0, int C1>
 __global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give XCD x the
+    // contiguous tile range [x*T/8, (x+1)*T/8): tiles that share an A row-panel then share one L2
+    // instead of every L2 fetching every panel.  Bijective for any T (cdna guide, T1).
     const int tile = blockIdx.x;
     int di = 0;
     for (int i = 1; i < batch.n; ++i)
         if (tile >= batch.d[i].tile_begin) di = i;
     const GemmDesc& d = batch.d[di];
-    const int lt = tile - d.tile_begin;
+    int lt = tile - d.tile_begin;
+    if (batch.xcd_remap) {  // within one problem (every XCD keeps its share of heavy and light problems)
+        const int T = d.tiles_m * d.tiles_n, q8 = T >> 3, r8 = T & 7;
+        const int xcd = lt & 7, idx = lt >> 3;
+        lt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
     if (C0 == C1 || d.cfg == C0)
         run_cfg<C0>(d, tm, tn, smem);
@@ -467,6 +475,8 @@ void finalize_batch(GemmBatch& b, int cfg) {
     }
     b.total_tiles = t;
     b.dbg = 0;
+    static const int remap = env_int("PSVAE_XCD_REMAP", 0);  // measured: no gain at these sizes (L2 fills are not the limiter)
+    b.xcd_remap = remap;
 }
 
 static size_t lds_bytes(const Cfg& c) {

@@ -53,6 +53,7 @@ struct GemmBatch {
     int n;
     int total_tiles;
     int dbg;  // reserved (0)
+    int xcd_remap;  // 1: XCD-aware tile order
 };
 
 // cfg = 1..num_gemm_configs() selects a (wave tile, wave layout, k-split, prefetch depth) config
