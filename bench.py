@@ -57,6 +57,71 @@ def cpu_baseline(D, Z, B, steps=40, warmup=3):
             "kind": "port", "sample": f"{n} steps of fwd+ELBO+bwd at B={B}, D={D}, Z={Z} (oracle, torch-CPU fp32)"}
 
 
+def bench_decode(args, world, rank, dev):
+    """cfg5: decode-only sampling (inference.py:22-25): z ~ N(0, I) from the device Philox stream, x_hat =
+    decoder(z).  Rows are split evenly over the ranks; no collective."""
+    from pseudo_speaker_vae_amd import ops
+    from pseudo_speaker_vae_amd.model import VAEModel
+    D, Z = args.input_dim, args.latent_dim
+    n = args.samples // world
+    torch.manual_seed(0)
+    m = VAEModel(D, Z)
+    dec = [p.detach().to(dev) for p in m.ordered_params()[12:]]
+    out = torch.empty(n, D, device=dev)
+    z = torch.empty(n, Z, device=dev)
+    scratch = torch.empty(1, dtype=torch.uint8, device=dev)
+
+    def step(i):
+        from pseudo_speaker_vae_amd import _ffi
+        _ffi.check(_ffi.lib().psvae_philox_normal_f32(z.data_ptr(), n * Z, 1234 + rank, i * ((n * Z + 3) // 4),
+                                                      torch.cuda.current_stream().cuda_stream), "philox")
+        ops.decode(z, dec, D, out=out, scratch=step.scratch)
+    import ctypes
+    from pseudo_speaker_vae_amd import _ffi
+    step.scratch = torch.empty(int(_ffi.lib().psvae_decode_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    steps, warm = max(1, min(args.steps, 20)), max(1, min(args.warmup, 3))
+    for i in range(warm):
+        step(i)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        step(warm + i)
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = t.tolist()
+    if rank == 0:
+        fpe = 2 * (Z * H + H * H + H * D)  # 851,968 FLOP per decoded embedding at cfg5 (SURVEY 8d)
+        achieved = fpe * n / (dev_ms / 1e3 / steps) / 1e12
+        print(json.dumps({
+            "metric": "speaker-embeddings/sec (decode)", "value": round(n * world * steps / wall, 1),
+            "unit": "speaker-embeddings/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg5: decode-only sampling, {n * world} rows per step ({n}/GPU), d_in={D} z={Z}, "
+                                   "Philox z on device + 3-layer decoder", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_embedding": fpe}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +132,9 @@ def main():
     ap.add_argument("--latent-dim", type=int, default=64)
     ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
     ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
+    ap.add_argument("--workload", choices=["train", "decode"], default="train",
+                    help="train = cfg2 (headline); decode = cfg5: decode-only sampling, --samples rows in total")
+    ap.add_argument("--samples", type=int, default=1_000_000, help="decode workload: rows over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -78,17 +146,24 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     from pseudo_speaker_vae_amd import build
-    if rank == 0:
-        build.build(verbose=False)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PSVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL smoke of the DDP path
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
-        dist.barrier()
+    if rank == 0:
+        build.build(verbose=False)  # no-op when the shipped .so matches the sources (content hash)
+    if use_dist:
+        dist.barrier()              # nobody loads the library before rank 0 has (re)built it
+    if args.workload == "decode":
+        return bench_decode(args, world, rank, dev)
 
     from pseudo_speaker_vae_amd.engine import TrainEngine
     D, Z, B = args.input_dim, args.latent_dim, args.batch
@@ -98,7 +173,7 @@ def main():
 
     mode = args.mode
     if mode == "auto":
-        mode = "graph" if world == 1 else "eager"
+        mode = "graph" if pg is None else "eager"
     if mode == "graph":
         eng.capture(x)
 
@@ -165,7 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, Z, B)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

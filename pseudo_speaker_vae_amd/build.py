@@ -24,12 +24,24 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libpsvae_hip.so")
 
 
+HASHFILE = LIB + ".srchash"
+
+
+def _src_hash() -> str:
+    """content hash of every source the library is built from (mtimes do not survive a repo snapshot)"""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(REPO, "include", "psvae.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(HASHFILE)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "psvae.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(HASHFILE).read().strip() != _src_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -50,10 +62,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for p, src in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)  # atomic: a concurrent loader never sees a half-written library
+    with open(HASHFILE, "w") as f:
+        f.write(_src_hash())
     return LIB
 
 

@@ -29,7 +29,7 @@ class GradAverager:
 
     def reduce_bucket(self, i: int):
         """start averaging bucket i (asynchronously); call once the kernels that WRITE it are enqueued"""
-        if self.world == 1:
+        if not dist.is_initialized():
             return
         if self.backend == "nccl":  # RCCL: averaging inside the collective
             w = dist.all_reduce(self.buckets[i], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)

@@ -85,8 +85,8 @@ class TrainEngine:
         self.loss3 = self.flat_grads[self.layout.loss_offset:self.layout.loss_offset + 3]
         # bucket 0 = encoders + loss scalars, bucket 1 = decoder (reduced first: its grads are ready first)
         self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group) \
-            if self.world > 1 else None
-        if self.world > 1:
+            if process_group is not None else None
+        if process_group is not None:
             broadcast_flat(self.flat_params, 0, process_group)
         self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
         self.outs = self.ws.new_outputs()
@@ -105,7 +105,7 @@ class TrainEngine:
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
         if self.flags == 0:  # default loss: the fused 14-launch sequence
             kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
-            if self.world == 1:
+            if self.averager is None:
                 ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
                 return
             ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
@@ -117,7 +117,7 @@ class TrainEngine:
         xh, mu, lv = ops.vae_forward(self.ws, x, self.params, eps, 0, 0, self.flags, outs=self.outs,
                                      rng_state=self.rng_state)
         ops.elbo(self.ws, x, xh, mu, lv, self.beta, self.flags, self.loss3)
-        if self.world == 1:
+        if self.averager is None:
             ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
                              flags=self.flags)
             return
@@ -142,7 +142,7 @@ class TrainEngine:
         ~20 kernels of a few microseconds each).  The captured step reads its batch from a static
         buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which
         the graph itself advances, so every replay draws fresh noise."""
-        if self.world != 1:
+        if self.averager is not None:
             raise _ffi.PsvaeError("graph capture is for the single-GPU path; RCCL collectives stay eager")
         self.static_x = x.detach().clone()
         side = torch.cuda.Stream(device=self.device)
