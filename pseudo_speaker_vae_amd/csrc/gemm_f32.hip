@@ -99,7 +99,9 @@ __device__ __forceinline__ int slot_index(int blk, int slot) { return KM ? T * s
 
 template <int TM, int TN, int WM, int WN, int KS, int D, bool AKM, bool BKM>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, float* __restrict__ smem) {
-    static_assert(WM * WN * KS == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN * KS;  // waves per workgroup: 4 or 8
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int NT = 64 * NW;
     constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
     constexpr int CQ = BN / 4;        // float4 per tile row
-    constexpr int RSTEP = NTHR / CQ;  // rows per pass (CQ <= 32 for every config)
+    constexpr int RSTEP = NT / CQ;    // rows per pass (CQ <= 32 for every config)
     const int c4 = tid % CQ, r0 = tid / CQ;
     const int col = n0 + 4 * c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -317,7 +319,12 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
         for (int o2 = 32; o2 > 0; o2 >>= 1) sq += __shfl_xor(sq, o2);
         if (lane == 0) red[wave] = sq;
         __syncthreads();
-        if (tid == 0) stg<float>(d.partials + tm * d.tiles_n + tn, (red[0] + red[1]) + (red[2] + red[3]));
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red[w];
+            stg<float>(d.partials + tm * d.tiles_n + tn, tot);
+        }
     }
     if (AKM && d.colsum != nullptr && tn == 0 && tid < BM) {
         float s = csum_s[tid];
@@ -341,6 +348,8 @@ PSVAE_CFG(6, 4, 4, 1, 1, 4, 2);  // 64x64   tile, k split 4
 PSVAE_CFG(7, 4, 4, 2, 2, 1, 2);  // 128x128 tile, no split (large batches)
 PSVAE_CFG(8, 1, 2, 1, 1, 4, 4);  // 16x32   tile, k split 4 (small outputs, long k)
 PSVAE_CFG(9, 4, 4, 1, 2, 2, 2);  // 64x128  tile, k split 2
+// (8-wave workgroups with k split 8 were measured too -- tools: profiles/r01 sweep -- and were never
+// faster than these; the tile code supports them: NW = WM*WN*KS may be 4 or 8)
 constexpr int NCFG = 9;
 
 struct Cfg {
@@ -370,7 +379,9 @@ __device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, float
 // machine and fill each other's bubbles.  (One kernel holding all nine configs made hipcc park the
 // fragment arrays in scratch; pairs compile clean.)
 template <int C0, int C1>
-__global__ __launch_bounds__(NTHR) void gemm_grouped_kernel(const GemmBatch batch) {
+__global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) void gemm_grouped_kernel(const GemmBatch batch) {
+    static_assert(CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS == CfgT<C1>::WM * CfgT<C1>::WN * CfgT<C1>::KS,
+                  "both configs of a launch need the same workgroup size");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so give XCD x the
     // contiguous tile range [x*T/8, (x+1)*T/8): tiles that share an A row-panel then share one L2
@@ -481,7 +492,7 @@ void finalize_batch(GemmBatch& b, int cfg) {
 
 static size_t lds_bytes(const Cfg& c) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
-    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 4) * sizeof(float);
+    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 8) * sizeof(float);
 }
 
 template <int C0, int C1>
@@ -493,7 +504,8 @@ static hipError_t launch_pair(const GemmBatch& b, size_t lds, hipStream_t stream
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1>), dim3(b.total_tiles), dim3(NTHR), lds, stream, b);
+    constexpr int NT = 64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS;
+    hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1>), dim3(b.total_tiles), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 
