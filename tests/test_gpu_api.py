@@ -194,3 +194,39 @@ def test_engine_adam_training_reduces_loss_and_matches_oracle_step():
         eng.optimizer_step()
     assert float(eng.loss3[0]) < 0.8 * first
     assert set(eng.state_dict()) == set(O.PARAM_KEYS)
+
+
+def test_conditional_model_matches_concat_definition():
+    """cfg3 extension (fp32): gather-add HIP path == literal one-hot concat (oracle definition), incl. grads."""
+    from pseudo_speaker_vae_amd.conditional import ConditionalVAEModel
+    D, Z, B = 256, 64, 96
+    torch.manual_seed(1)
+    m = ConditionalVAEModel(D, Z).to(DEV)
+    p_cat = {k: v.cpu() for k, v in m.to_concat_state_dict().items()}
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    gender = torch.randint(-1, 3, (B,))
+    age = torch.randint(-1, 3, (B,))
+    total, recon, kl, xh, mu, lv = m.elbo_step(x.to(DEV), gender, age, beta=0.8, eps=eps.to(DEV))
+    total.backward()
+    pc = {k: v.clone().requires_grad_() for k, v in p_cat.items()}
+    a = O.forward_cond_concat(pc, x, eps, gender, age)
+    r_ref, k_ref, t_ref = O.elbo(a["x_hat"], x, a["mu"], a["logvar"], 0.8)
+    t_ref.backward()
+    assert_close(xh.detach().cpu(), a["x_hat"].detach(), REL_TOL, "x_hat")
+    assert abs(float(total) - float(t_ref)) < REL_TOL
+    for blk, n_in in (("encoder_mu", D), ("encoder_sigma", D), ("decoder", Z)):
+        gW = pc[f"{blk}.0.weight"].grad
+        assert_close(dict(m.named_parameters())[f"{blk}.0.weight"].grad.cpu(), gW[:, :n_in], 3e-4, blk + " W")
+        assert_close(m.cond[blk].grad.cpu(), gW[:, n_in:].t(), 3e-4, blk + " table")
+    for k in ("encoder_mu.2.weight", "decoder.4.bias", "encoder_sigma.4.weight"):
+        assert_close(dict(m.named_parameters())[k].grad.cpu(), pc[k].grad, 3e-4, k)
+    # decode with labels + round trip of the concat parameterisation
+    z = torch.randn(B, Z)
+    out = m.decode(z.to(DEV), gender, age)
+    zc = torch.cat([z, O.onehot_cond(gender, age)], dim=1)
+    _, _, ref = O._mlp3(zc, p_cat, "decoder")
+    assert_close(out.cpu(), ref, REL_TOL, "conditional decode")
+    m2 = ConditionalVAEModel(D, Z)
+    m2.from_concat_state_dict(p_cat)
+    for (k, v), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k == k2 and torch.equal(v.cpu(), v2), k
