@@ -27,6 +27,7 @@ if REPO not in sys.path:
 
 H = 512
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (spec figure without 2:1 sparsity)
 
 
 def flop_per_embedding(D: int, Z: int) -> int:
@@ -132,6 +133,9 @@ def main():
     ap.add_argument("--latent-dim", type=int, default=64)
     ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
     ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = config 3 arithmetic (bf16 MFMA operands, fp32 accumulate and master weights)")
+    ap.add_argument("--cond", action="store_true", help="config 3: one-hot gender+age conditioning (needs --dtype bf16)")
     ap.add_argument("--workload", choices=["train", "decode"], default="train",
                     help="train = cfg2 (headline); decode = cfg5: decode-only sampling, --samples rows in total")
     ap.add_argument("--samples", type=int, default=1_000_000, help="decode workload: rows over all GPUs")
@@ -167,14 +171,25 @@ def main():
 
     from pseudo_speaker_vae_amd.engine import TrainEngine
     D, Z, B = args.input_dim, args.latent_dim, args.batch
-    eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=pg)
+    eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=pg, dtype=args.dtype,
+                      conditional=args.cond)
     g = torch.Generator().manual_seed(1234 + rank)  # each rank its own shard of synthetic rows
     x = torch.randn(B, D, generator=g).to(dev)
+    if args.cond:
+        eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
 
     mode = args.mode
     if mode == "auto":
-        mode = "graph" if pg is None else "eager"
-    if mode == "graph":
+        mode = "graph"
+    if mode == "graph" and pg is not None:
+        mode = "graph-ddp"  # two captured halves around the eager RCCL all-reduces
+        eng.capture_ddp(x)
+
+        def step():
+            eng.replay_ddp()
+            if args.with_adam:
+                eng.optimizer_step()
+    elif mode == "graph":
         eng.capture(x)
 
         def step():
@@ -215,9 +230,10 @@ def main():
     if rank == 0:
         traffic = None  # L2-fill bytes per step from the committed PMC passes (profiles/, cfg2 shape only)
         pmc = os.path.join(REPO, "profiles", "r01_cfg2_pmc.json")
-        if (D, Z, B) == (256, 64, 1024) and os.path.exists(pmc):
+        if (D, Z, B) == (256, 64, 1024) and args.dtype == "f32" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_step"]
-        fpe = flop_per_embedding(D, Z)
+        fpe = flop_per_embedding(D, Z) + (2 * 3 * 2 * 6 * H if args.cond else 0)  # +6 one-hot columns x3, fwd+wgrad
+        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         step_s_dev = dev_ms / 1e3 / args.steps
         achieved = fpe * B / step_s_dev / 1e12  # per GPU, over the HIP-event duration of the step
         out = {
@@ -227,13 +243,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: VAE fwd+ELBO+bwd{'+Adam' if args.with_adam else ''}"
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{'cfg3' if args.dtype == 'bf16' else 'cfg2'}: "
+                                   f"{'conditional (one-hot gender+age) ' if args.cond else ''}"
+                                   f"VAE fwd+ELBO+bwd{'+Adam' if args.with_adam else ''}"
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
-                                   f"batch={B}/GPU, global_batch={B * world}, fp32",
+                                   f"batch={B}/GPU, global_batch={B * world}, "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
                        "launch": mode, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5)},
             "loss": [round(v, 6) for v in loss],
         }

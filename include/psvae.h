@@ -138,6 +138,19 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
                          float* logvar, float beta, const float* grad_loss /* nullable = 1 */,
                          const psvae_grads* grads, float* loss3, void* scratch, uint32_t phases, void* stream);
 
+/* bf16 variant of psvae_train_step_f32 (BASELINE config 3: bf16 MFMA operands, fp32 accumulate, fp32 master
+ * weights, gradients and loss).  D and Z must be multiples of 32.  x, params, grads, outputs, eps_out[B,Z] and
+ * z_out[B,Z] are fp32; all bf16 intermediates live in `scratch` (psvae_bf16_scratch_bytes), which the caller
+ * must ZERO-FILL once (the batch padding of the transposed copies is read, never written).  cond (nullable)
+ * adds the one-hot gather tables. */
+size_t psvae_bf16_scratch_bytes(const psvae_dims* dims);
+int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params,
+                          const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,
+                          uint64_t seed, uint64_t offset, uint64_t* rng_state /* nullable */, float* eps_out,
+                          float* z_out, float* x_hat, float* mu, float* logvar, float beta,
+                          const float* grad_loss /* nullable = 1 */, const psvae_grads* grads, float* loss3,
+                          void* scratch, void* stream);
+
 /* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
  * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
 size_t psvae_decode_scratch_bytes(int64_t N);

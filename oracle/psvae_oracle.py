@@ -426,3 +426,72 @@ def langevin(layers, z0, noises, target: int, step_size: float, noise_weight: fl
         z = z + 0.5 * step_size ** 2 * grad + step_size * noise_weight * noises[t]  # inference.py:97
         hist.append(z.clone())
     return z, hist
+
+
+# --------------------------------------------------------------------------------------
+# bf16 path (BASELINE config 3): bf16 MFMA operands, fp32 accumulation, fp32 master weights.
+# The reference has no bf16 code: this emulation DEFINES the rounding points of the HIP bf16 path
+# (every GEMM operand is rounded to bf16 once, where the producing kernel stores it; accumulators,
+# biases, mu / logvar / x_hat, the loss and all parameter gradients stay fp32).  Parity unpinned by the
+# reference; pinned to the fp32 oracle only through the bf16 tolerance in tests/test_gpu_bf16.py.
+# --------------------------------------------------------------------------------------
+def bf(t: torch.Tensor) -> torch.Tensor:
+    return t.bfloat16().float()
+
+
+def train_step_bf16(p, x, eps, beta: float = 1.0, go: float = 1.0, tabs=None, gender=None, age=None):
+    B, D = x.shape
+    W = {k: bf(v) for k, v in p.items() if k.endswith("weight")}
+    xb = bf(x)
+
+    def rows(blk, n_out):
+        out = torch.zeros(B, n_out)
+        if tabs is not None:
+            tab = tabs[f"cond.{blk}"]
+            for lab, base, n in ((gender, 0, N_GENDER), (age, N_GENDER, N_AGE)):
+                ok = (lab >= 0) & (lab < n)
+                out[ok] += tab[base + lab[ok].long()]
+        return out
+
+    def enc(blk):
+        h1 = bf(torch.relu(xb @ W[f"{blk}.0.weight"].t() + p[f"{blk}.0.bias"] + rows(blk, HIDDEN)))
+        h2 = bf(torch.relu(h1 @ W[f"{blk}.2.weight"].t() + p[f"{blk}.2.bias"]))
+        return h1, h2, h2 @ W[f"{blk}.4.weight"].t() + p[f"{blk}.4.bias"]
+
+    h1m, h2m, mu = enc("encoder_mu")
+    h1s, h2s, lv = enc("encoder_sigma")
+    z = mu + torch.exp(0.5 * lv) * eps
+    zb = bf(z)
+    d1 = bf(torch.relu(zb @ W["decoder.0.weight"].t() + p["decoder.0.bias"] + rows("decoder", HIDDEN)))
+    d2 = bf(torch.relu(d1 @ W["decoder.2.weight"].t() + p["decoder.2.bias"]))
+    xh = d2 @ W["decoder.4.weight"].t() + p["decoder.4.bias"]
+    recon, kl, total = elbo(xh, x, mu, lv, beta)
+    g = {}
+    gy = bf(go * 2.0 * (xh - x) / (10.0 * B * D))
+
+    def back(gyb, inp, a1, a2, blk, need_dx):
+        g[f"{blk}.4.weight"] = gyb.t() @ a2
+        g[f"{blk}.4.bias"] = gyb.sum(0)
+        da2 = bf((gyb @ W[f"{blk}.4.weight"]) * (a2 > 0))
+        g[f"{blk}.2.weight"] = da2.t() @ a1
+        g[f"{blk}.2.bias"] = da2.sum(0)
+        da1 = bf((da2 @ W[f"{blk}.2.weight"]) * (a1 > 0))
+        g[f"{blk}.0.weight"] = da1.t() @ inp
+        g[f"{blk}.0.bias"] = da1.sum(0)
+        return da1, ((da1 @ W[f"{blk}.0.weight"]) if need_dx else None)
+
+    dd1, gz = back(gy, zb, d1, d2, "decoder", True)
+    gmu = bf(gz + go * beta * mu / B)
+    glv = bf(gz * eps * 0.5 * torch.exp(0.5 * lv) + go * beta * (lv.exp() - 1.0) / (2.0 * B))
+    dh1m, _ = back(gmu, xb, h1m, h2m, "encoder_mu", False)
+    dh1s, _ = back(glv, xb, h1s, h2s, "encoder_sigma", False)
+    tg = None
+    if tabs is not None:
+        tg = {}
+        for blk, dy in (("encoder_mu", dh1m), ("encoder_sigma", dh1s), ("decoder", dd1)):
+            t = torch.zeros(COND_DIM, HIDDEN)
+            for lab, base, n in ((gender, 0, N_GENDER), (age, N_GENDER, N_AGE)):
+                for j in range(n):
+                    t[base + j] = dy[lab == j].sum(0)
+            tg[f"cond.{blk}"] = t
+    return dict(recon=recon, kl=kl, total=total), {k: g[k] for k in PARAM_KEYS}, dict(x_hat=xh, mu=mu, logvar=lv, z=z), tg

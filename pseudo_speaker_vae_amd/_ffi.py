@@ -26,7 +26,7 @@ ABI_VERSION = 1
 SYMBOLS = (
     "psvae_version", "psvae_debug_force_tile", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
-    "psvae_decode_scratch_bytes",
+    "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32",
 )
 
@@ -87,6 +87,11 @@ def lib() -> C.CDLL:
                                      vp, vp, vp, vp, vp, vp, C.c_int, f32, vp, C.POINTER(Grads), vp, vp, u32, u32, vp]
     L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
                                        vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
+    L.psvae_bf16_scratch_bytes.restype = C.c_size_t
+    L.psvae_bf16_scratch_bytes.argtypes = [C.POINTER(Dims)]
+    L.psvae_train_step_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), vp, u64, u64, vp, vp,
+                                        vp, vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, vp]
+    L.psvae_train_step_bf16.restype = C.c_int
     L.psvae_decode_f32.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp, u32, vp]
     L.psvae_gemm_f32.argtypes = [C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp, vp, C.c_int, C.c_int, vp]
     f64 = C.c_double

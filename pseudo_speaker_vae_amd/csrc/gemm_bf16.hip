@@ -1,0 +1,402 @@
+// bf16 MFMA path (BASELINE config 3: bf16 operands, fp32 accumulate, fp32 master weights).
+//
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane for BOTH operands, i.e. both operands
+// k-contiguous in memory.  So the bf16 path keeps every activation / gradient / weight tensor in TWO bf16
+// layouts, [rows][features] and [features][rows(padded to 32)], written by the producing kernel's epilogue,
+// and every GEMM is the same "NT" product C[m][n] = sum_k A[m][k] * B[n][k]:
+//   forward  h' = h W^T        A = h  [B,K]        B = W   [N,K]
+//   dgrad    dX = dY W         A = dY [B,N]        B = W^T [K,N]
+//   wgrad    dW = dY^T X       A = dY^T [N,Bpad]   B = X^T [K,Bpad]      (contraction over the padded batch)
+// Structure as the fp32 kernel (csrc/gemm_f32.hip): register-direct fragments (one 16-B load = 8 bf16 per
+// lane per 16-row block per 32-k chunk, no permutation needed), D chunks in flight, split-K across the 4
+// waves, one LDS meeting point for the k slices, fused epilogue writing fp32 and/or both bf16 layouts.
+#include <hip/hip_bf16.h>
+
+#include "psvae_common.h"
+
+namespace psvae {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define PSVAE_GLOBAL __attribute__((address_space(1)))
+template <typename V, typename P>
+__device__ __forceinline__ V ldgb(const P* p) {
+    return *reinterpret_cast<const PSVAE_GLOBAL V*>(reinterpret_cast<uintptr_t>(p));
+}
+template <typename V, typename P>
+__device__ __forceinline__ void stgb(P* p, const V& v) {
+    *reinterpret_cast<PSVAE_GLOBAL V*>(reinterpret_cast<uintptr_t>(p)) = v;
+}
+
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even, NaN preserved (plain cast)
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<u16*>(&h);
+}
+__device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned)u) << 16); }
+
+template <int TM, int TN, int WM, int WN, int KS, int D>
+__device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int tn, float* __restrict__ smem) {
+    constexpr int NW = WM * WN * KS;
+    static_assert(NW == 4, "4 waves per workgroup");
+    constexpr int NT = 256;
+    constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wave / (WM * WN), ws = wave % (WM * WN);
+    const int wm = ws / WN, wn = ws % WN;
+    const int r = lane & 15, q = lane >> 4;
+    const int M = d.M, N = d.N, K = d.K;  // K % 32 == 0 (host pads the contracted dimension)
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int am = m0 + wm * 16 * TM, bn = n0 + wn * 16 * TN;
+    const u16* __restrict__ A = d.A;
+    const u16* __restrict__ B = d.B;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum[TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) csum[m] = 0.f;
+    const bool do_colsum = (d.colsum != nullptr) && (tn == 0) && (wn == 0);
+
+    // row pointers (rows clamped: they only feed outputs the epilogue never stores)
+    const u16* pa[TM];
+    const u16* pb[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int row = am + 16 * m + r;
+        row = row < M ? row : M - 1;
+        pa[m] = A + (size_t)row * d.lda + 8 * q;
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        int row = bn + 16 * n + r;
+        row = row < N ? row : N - 1;
+        pb[n] = B + (size_t)row * d.ldb + 8 * q;
+    }
+    const int nc = K >> 5;  // 32-k chunks
+    const int per = (nc + KS - 1) / KS;
+    const int cbeg = ks * per;
+    const int cend = (cbeg + per < nc) ? cbeg + per : nc;
+
+    bf16x8 fa[D][TM], fb[D][TN];
+    auto load = [&](int s, int c) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) fa[s][m] = ldgb<bf16x8>(pa[m] + 32 * c);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[s][n] = ldgb<bf16x8>(pb[n] + 32 * c);
+    };
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][m], fb[s][n], acc[m][n], 0, 0, 0);
+        if (do_colsum) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[m] += bf2f((u16)fa[s][m][e]);
+        }
+    };
+    int c = cbeg;
+    const int nfull = cend > cbeg ? (cend - cbeg) / D : 0;
+    if (nfull > 0) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) load(s, cbeg + s);
+        for (int g = 1; g < nfull; ++g) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                mma(s);
+                load(s, cbeg + g * D + s);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < D; ++s) mma(s);
+        c = cbeg + nfull * D;
+    }
+    for (; c < cend; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (c + s < cend) load(s, c + s);
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (c + s < cend) mma(s);
+    }
+
+    // ---- epilogue ----
+    constexpr int SC = BN + 4;
+    float* __restrict__ Cs = smem + ks * (BM * SC);
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = wm * 16 * TM + 16 * m + 4 * q + j;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) Cs[lr * SC + wn * 16 * TN + 16 * n + r] = acc[m][n][j];
+        }
+    float* __restrict__ csum_s = smem + KS * (BM * SC);
+    if (do_colsum) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            float s = csum[m];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (q == 0) csum_s[ks * BM + wm * 16 * TM + 16 * m + r] = s;
+        }
+    }
+    __syncthreads();
+    const int epi = d.epi;
+    constexpr int CQ = BN / 4;
+    constexpr int RSTEP = NT / CQ;
+    const int c4 = tid % CQ, r0 = tid / CQ;
+    const int col = n0 + 4 * c4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < N) bias4[e] = ldgb<float>(d.bias + col + e);
+    }
+    float sq = 0.f;
+    const float gsc = (epi == BEPI_RECON) ? d.scale * (d.go ? ldgb<float>(d.go) : 1.0f) : 0.f;
+    const bool colfull = col + 3 < N;
+#pragma unroll
+    for (int rr = 0; rr < BM; rr += RSTEP) {
+        const int lr = rr + r0;
+        const int row = m0 + lr;
+        if (lr >= BM) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * SC + 4 * c4);
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 4 * c4);
+        if (row < M && col < N) {
+            v += bias4;
+            if (d.ctab) {
+                const int g = d.gender[row], a = d.age[row];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e < N) {
+                        if (g >= 0 && g < 3) v[e] += ldgb<float>(d.ctab + (size_t)g * N + col + e);
+                        if (a >= 0 && a < 3) v[e] += ldgb<float>(d.ctab + (size_t)(3 + a) * N + col + e);
+                    }
+                }
+            }
+            if (epi == BEPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (epi == BEPI_MASK) {  // ReLU backward: mask = saved bf16 activation [M, ldcb]
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) v[e] = bf2f(ldgb<u16>(d.mask + (size_t)row * d.ldmask + col + e)) > 0.f ? v[e] : 0.f;
+            }
+            if (d.Cf) {  // fp32 output (final outputs, wgrads)
+                float* p = d.Cf + (size_t)row * d.ldcf + col;
+                if (colfull && ((d.ldcf & 3) == 0)) {
+                    stgb<f32x4>(p, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) stgb<float>(p + e, v[e]);
+                }
+            }
+            if (epi == BEPI_RECON) {  // v = x_hat: emit the MSE gradient instead of v into the bf16 outputs
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float df = (col + e < N) ? v[e] - ldgb<float>(d.target + (size_t)row * d.ldcf + col + e) : 0.f;
+                    sq += df * df;
+                    v[e] = gsc * df;
+                }
+            }
+            if (d.Cb) {
+                u16* p = d.Cb + (size_t)row * d.ldcb + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) stgb<u16>(p + e, f2bf(v[e]));
+            }
+        } else {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (d.CbT) *reinterpret_cast<f32x4*>(smem + lr * SC + 4 * c4) = v;  // final values for the transposed pass
+    }
+    if (d.CbT) {  // transposed bf16 copy [N][ldt]: column reads of the finished tile, 4 rows per lane
+        __syncthreads();
+        constexpr int MQ = BM / 4;
+        for (int i = tid; i < BN * MQ; i += NT) {
+            const int n = i / MQ, mq = i % MQ;
+            const int gn = n0 + n, gm = m0 + 4 * mq;
+            if (gn >= N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gm + e < M) stgb<u16>(d.CbT + (size_t)gn * d.ldt + gm + e, f2bf(smem[(4 * mq + e) * SC + n]));
+        }
+    }
+    if (epi == BEPI_RECON) {
+        float* __restrict__ red = smem + KS * (BM * SC) + KS * BM;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sq += __shfl_xor(sq, o2);
+        __syncthreads();
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) stgb<float>(d.partials + tm * d.tiles_n + tn, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+    if (d.colsum != nullptr && tn == 0 && tid < BM) {
+        float s = csum_s[tid];
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) s += csum_s[k2 * BM + tid];
+        if (m0 + tid < M) stgb<float>(d.colsum + m0 + tid, s);
+    }
+}
+
+template <int TM, int TN, int WM, int WN, int KS, int D>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = blockIdx.x;
+    int di = 0;
+    for (int i = 1; i < batch.n; ++i)
+        if (tile >= batch.d[i].tile_begin) di = i;
+    const GemmDescBf& d = batch.d[di];
+    const int lt = tile - d.tile_begin;
+    const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
+    gemm_tile_bf16<TM, TN, WM, WN, KS, D>(d, tm, tn, smem);
+}
+
+template <int TM, int TN, int WM, int WN, int KS, int D>
+static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
+    constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
+    constexpr size_t lds = (size_t)(KS * BM * (BN + 4) + KS * BM + 8) * sizeof(float);
+    int t = 0;
+    for (int i = 0; i < b.n; ++i) {
+        b.d[i].tiles_m = (b.d[i].M + BM - 1) / BM;
+        b.d[i].tiles_n = (b.d[i].N + BN - 1) / BN;
+        b.d[i].tile_begin = t;
+        t += b.d[i].tiles_m * b.d[i].tiles_n;
+    }
+    b.total_tiles = t;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, WM, WN, KS, D>), dim3(t), dim3(256), lds, stream, b);
+    return hipGetLastError();
+}
+
+// config choice: wide register tiles (the bf16 pipe is 16x faster than fp32, the fragment loads are the
+// bottleneck: 64x64 per wave halves the bytes per MFMA of 32x32); k split only when the tile count is low
+hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
+    if (b.n <= 0) return hipSuccess;
+    long t44 = 0, t22 = 0;
+    int kmin = 1 << 30;
+    for (int i = 0; i < b.n; ++i) {
+        t44 += (long)((b.d[i].M + 63) / 64) * ((b.d[i].N + 63) / 64);
+        t22 += (long)((b.d[i].M + 31) / 32) * ((b.d[i].N + 31) / 32);
+        kmin = b.d[i].K < kmin ? b.d[i].K : kmin;
+    }
+    if (t44 >= 192) {
+        if (t44 >= 1024 && kmin <= 1024) return launch_bf<4, 4, 2, 2, 1, 2>(b, stream);  // 128x128 tiles, no split
+        return launch_bf<4, 4, 1, 1, 4, 2>(b, stream);                                    // 64x64, k split 4
+    }
+    if (t22 >= 128) return launch_bf<2, 2, 1, 1, 4, 4>(b, stream);                         // 32x32, k split 4
+    return launch_bf<1, 2, 1, 1, 4, 4>(b, stream);                                         // 16x32, k split 4
+}
+
+// ---- fp32 [R,C] -> bf16 [R,C] and bf16 [C, ldt] (32x32 LDS tile), several tensors per launch -----------
+struct CastArgs {
+    const float* src[12];
+    u16* dst[12];
+    u16* dstT[12];
+    int R[12], Cc[12], ld[12], ldt[12], tile_begin[12];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const CastArgs a) {
+    __shared__ float tile[32][33];
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.tile_begin[i]) pi = i;
+    const int R = a.R[pi], Cc = a.Cc[pi];
+    const int tiles_c = (Cc + 31) / 32;
+    const int lt = blockIdx.x - a.tile_begin[pi];
+    const int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 32;
+    const float* __restrict__ src = a.src[pi];
+    u16* __restrict__ dst = a.dst[pi];
+    u16* __restrict__ dstT = a.dstT[pi];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        const float v = (rr < R && cc < Cc) ? src[(size_t)rr * a.ld[pi] + cc] : 0.f;
+        tile[ty + 8 * i][tx] = v;
+        if (dst && rr < R && cc < Cc) dst[(size_t)rr * Cc + cc] = f2bf(v);
+    }
+    __syncthreads();
+    if (dstT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+            if (cc < Cc && rr < R) dstT[(size_t)cc * a.ldt[pi] + rr] = f2bf(tile[tx][ty + 8 * i]);
+        }
+    }
+}
+
+hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* const* dstT, const int* R, const int* Cc,
+                                 const int* ld, const int* ldt, int n, hipStream_t s) {
+    CastArgs a{};
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.dstT[i] = dstT[i];
+        a.R[i] = R[i]; a.Cc[i] = Cc[i]; a.ld[i] = ld[i]; a.ldt[i] = ldt[i];
+        a.tile_begin[i] = t;
+        t += ((R[i] + 31) / 32) * ((Cc[i] + 31) / 32);
+    }
+    a.n = n;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(t), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// conditional-table gradients from bf16 dY (see cond_colsum_kernel in elementwise.hip)
+struct CondSumArgsBf {
+    const u16* dY[3];
+    float* gtab[3];
+};
+__global__ __launch_bounds__(256) void cond_colsum_bf16_kernel(CondSumArgsBf a, const int32_t* __restrict__ gender,
+                                                               const int32_t* __restrict__ age, int B, int N) {
+    __shared__ float sh[4][6][64];
+    const u16* __restrict__ dY = a.dY[blockIdx.y];
+    float* __restrict__ gt = a.gtab[blockIdx.y];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (int b = rl; b < B; b += 4) {
+            const float v = bf2f(dY[(size_t)b * N + col]);
+            const int g = gender[b], ag = age[b];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] += (g == c) ? v : 0.f;
+                acc[3 + c] += (ag == c) ? v : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sh[rl][c][cl] = acc[c];
+    __syncthreads();
+    if (rl == 0 && col < N) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) gt[(size_t)c * N + col] = (sh[0][c][cl] + sh[1][c][cl]) + (sh[2][c][cl] + sh[3][c][cl]);
+    }
+}
+
+hipError_t launch_cond_colsum_bf16(const u16* const* dY, float* const* gtab, int nprob, const int32_t* gender,
+                                   const int32_t* age, int B, int N, hipStream_t s) {
+    CondSumArgsBf a{};
+    for (int i = 0; i < nprob; ++i) { a.dY[i] = dY[i]; a.gtab[i] = gtab[i]; }
+    hipLaunchKernelGGL(cond_colsum_bf16_kernel, dim3((N + 63) / 64, nprob), dim3(256), 0, s, a, gender, age, B, N);
+    return hipGetLastError();
+}
+
+}  // namespace psvae

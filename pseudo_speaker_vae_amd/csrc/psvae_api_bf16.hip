@@ -1,0 +1,251 @@
+// extern "C" entry points of the bf16 path (BASELINE config 3): bf16 MFMA operands, fp32 accumulation,
+// fp32 master weights / gradients / loss.  One call = one training pass; see gemm_bf16.hip for the layout
+// idea (every tensor in two bf16 layouts so that every GEMM has both operands k-contiguous).
+#include "psvae_common.h"
+
+using namespace psvae;
+typedef unsigned short u16;
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define RET_IF(e)                            \
+    do {                                     \
+        hipError_t _e = (e);                 \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+struct BfScratch {
+    // weights: row-major bf16 copies Wb[i] ([out,in]) and transposed WbT[i] ([in,out]) of the 9 matrices
+    u16 *Wb[9], *WbT[9];
+    u16 *xb, *xbT;                                  // [B,D], [D,Bp]
+    u16 *h1m, *h1mT, *h2m, *h2mT, *h1s, *h1sT, *h2s, *h2sT, *d1, *d1T, *d2, *d2T;  // [B,H] / [H,Bp]
+    u16 *zb, *zbT;                                  // [B,Z], [Z,Bp]
+    u16 *gy, *gyT;                                  // [B,D], [D,Bp]
+    u16 *dd2, *dd2T, *dd1, *dd1T, *dh2m, *dh2mT, *dh2s, *dh2sT, *dh1m, *dh1mT, *dh1s, *dh1sT;  // [B,H] / [H,Bp]
+    u16 *gmu, *gmuT, *glv, *glvT;                   // [B,Z] / [Z,Bp]
+    float *gz, *gmu_f, *glv_f, *kl_partials, *recon_partials;
+    int n_recon_max;
+    size_t bytes;
+};
+
+// dims of the 9 weight matrices in params order (weights are params[0,2,4, 6,8,10, 12,14,16])
+inline void weight_dims(int D, int Z, int (&out_)[9], int (&in_)[9]) {
+    const int o[9] = {H, H, Z, H, H, Z, H, H, D};
+    const int i[9] = {D, H, H, D, H, H, Z, H, H};
+    for (int k = 0; k < 9; ++k) { out_[k] = o[k]; in_[k] = i[k]; }
+}
+
+BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
+    BfScratch s{};
+    size_t off = 0;
+    const int64_t Bp = (B + 31) / 32 * 32;
+    auto take = [&](size_t nbytes) {
+        char* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align_up(nbytes, 256);
+        return p;
+    };
+    auto tb = [&](size_t n) { return reinterpret_cast<u16*>(take(n * 2)); };
+    auto tf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
+    int wo[9], wi[9];
+    weight_dims((int)D, (int)Z, wo, wi);
+    for (int k = 0; k < 9; ++k) {
+        s.Wb[k] = tb((size_t)wo[k] * wi[k]);
+        s.WbT[k] = tb((size_t)wi[k] * wo[k]);
+    }
+    s.xb = tb(B * D); s.xbT = tb(D * Bp);
+    u16** hs[] = {&s.h1m, &s.h2m, &s.h1s, &s.h2s, &s.d1, &s.d2, &s.dd2, &s.dd1, &s.dh2m, &s.dh2s, &s.dh1m, &s.dh1s};
+    u16** hts[] = {&s.h1mT, &s.h2mT, &s.h1sT, &s.h2sT, &s.d1T, &s.d2T, &s.dd2T, &s.dd1T, &s.dh2mT, &s.dh2sT, &s.dh1mT, &s.dh1sT};
+    for (int k = 0; k < 12; ++k) { *hs[k] = tb(B * H); *hts[k] = tb((size_t)H * Bp); }
+    s.zb = tb(B * Z); s.zbT = tb(Z * Bp);
+    s.gy = tb(B * D); s.gyT = tb(D * Bp);
+    s.gmu = tb(B * Z); s.gmuT = tb(Z * Bp); s.glv = tb(B * Z); s.glvT = tb(Z * Bp);
+    s.gz = tf(B * Z); s.gmu_f = tf(B * Z); s.glv_f = tf(B * Z);
+    s.kl_partials = tf((size_t)reparam_blocks(B * Z));
+    s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));
+    s.recon_partials = tf((size_t)s.n_recon_max);
+    s.bytes = off;
+    return s;
+}
+
+inline GemmDescBf bdesc(int M, int N, int K, const u16* A, int lda, const u16* B, int ldb) {
+    GemmDescBf d{};
+    d.A = A; d.B = B; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb;
+    d.epi = BEPI_NONE; d.scale = 1.f;
+    return d;
+}
+inline void addb(GemmBatchBf& b, const GemmDescBf& d) { b.d[b.n++] = d; }
+
+}  // namespace
+
+extern "C" {
+
+size_t psvae_bf16_scratch_bytes(const psvae_dims* dims) {
+    if (!dims || dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return 0;
+    return carve_bf(nullptr, dims->B, dims->D, dims->Z).bytes;
+}
+
+// One training pass in bf16 (config 3).  x, params, grads, loss3, x_hat, mu, logvar are fp32; every
+// intermediate lives in `scratch` (psvae_bf16_scratch_bytes; MUST be zero-filled once by the caller: the
+// batch padding of the transposed copies is read but never written).  D and Z must be multiples of 32.
+int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                          const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
+                          float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
+                          const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
+    if (!dims || !x || !params || !grads || !x_hat || !mu || !logvar || !loss3 || !scratch || !eps_out || !z_out)
+        return PSVAE_ERR_NULL;
+    if (dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return PSVAE_ERR_SHAPE;
+    if ((dims->D & 31) || (dims->Z & 31)) return PSVAE_ERR_SHAPE;  // contracted dims must be whole 32-k chunks
+    for (int i = 0; i < PSVAE_NPARAM; ++i)
+        if (!params->p[i] || !grads->g[i]) return PSVAE_ERR_NULL;
+    const bool has_cond = cond && cond->tab[0];
+    if (has_cond && (!cond->gender || !cond->age || !cond->tab[1] || !cond->tab[2] || !cond->gtab[0] ||
+                     !cond->gtab[1] || !cond->gtab[2]))
+        return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    const int Bp = (B + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* P = params->p;
+    float* const* G = grads->g;
+    BfScratch sc = carve_bf(scratch, B, D, Z);
+    int wo[9], wi[9];
+    weight_dims(D, Z, wo, wi);
+
+    {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
+        const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
+        for (int k = 0; k < 9; ++k) {
+            src[k] = P[2 * k]; dst[k] = sc.Wb[k]; dstT[k] = sc.WbT[k];
+            R[k] = wo[k]; C[k] = wi[k]; ld[k] = wi[k]; ldt[k] = wo[k];
+        }
+        src[9] = x; dst[9] = sc.xb; dstT[9] = sc.xbT; R[9] = B; C[9] = D; ld[9] = D; ldt[9] = Bp;
+        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s));
+    }
+    auto hidden = [&](const u16* A, int K, int wk, u16* out, u16* outT, const float* ctab) {
+        GemmDescBf d = bdesc(B, H, K, A, K, sc.Wb[wk], K);
+        d.bias = P[2 * wk + 1]; d.epi = BEPI_RELU; d.Cb = out; d.ldcb = H; d.CbT = outT; d.ldt = Bp;
+        if (ctab) { d.ctab = ctab; d.gender = cond->gender; d.age = cond->age; }
+        return d;
+    };
+    {  // encoder layer 1 (model.py:15,23)
+        GemmBatchBf b{};
+        addb(b, hidden(sc.xb, D, 0, sc.h1m, sc.h1mT, has_cond ? cond->tab[0] : nullptr));
+        addb(b, hidden(sc.xb, D, 3, sc.h1s, sc.h1sT, has_cond ? cond->tab[1] : nullptr));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, hidden(sc.h1m, H, 1, sc.h2m, sc.h2mT, nullptr));
+        addb(b, hidden(sc.h1s, H, 4, sc.h2s, sc.h2sT, nullptr));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {  // heads: fp32 outputs
+        GemmBatchBf b{};
+        GemmDescBf dm = bdesc(B, Z, H, sc.h2m, H, sc.Wb[2], H);
+        dm.bias = P[5]; dm.Cf = mu; dm.ldcf = Z;
+        GemmDescBf ds = bdesc(B, Z, H, sc.h2s, H, sc.Wb[5], H);
+        ds.bias = P[11]; ds.Cf = logvar; ds.ldcf = Z;
+        addb(b, dm); addb(b, ds);
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
+                             (int64_t)B * Z, s));
+    {
+        const float* src[1] = {z_out}; u16* dst[1] = {sc.zb}; u16* dstT[1] = {sc.zbT};
+        int R[1] = {B}, C[1] = {Z}, ld[1] = {Z}, ldt[1] = {Bp};
+        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 1, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, hidden(sc.zb, Z, 6, sc.d1, sc.d1T, has_cond ? cond->tab[2] : nullptr));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, hidden(sc.d1, H, 7, sc.d2, sc.d2T, nullptr));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    int n_recon = 0;
+    {  // decoder output (fp32) + MSE gradient (bf16, both layouts) + MSE partial sums
+        GemmBatchBf b{};
+        GemmDescBf d = bdesc(B, D, H, sc.d2, H, sc.Wb[8], H);
+        d.bias = P[17]; d.Cf = x_hat; d.ldcf = D; d.epi = BEPI_RECON; d.target = x; d.go = grad_loss;
+        d.scale = 2.0f / (10.0f * (float)B * (float)D);
+        d.Cb = sc.gy; d.ldcb = D; d.CbT = sc.gyT; d.ldt = Bp; d.partials = sc.recon_partials;
+        addb(b, d);
+        RET_IF(launch_gemm_batch_bf16(b, s));
+        n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
+        if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
+    }
+    // backward: wgrad  dW[o][i] = sum_b dY^T[o][b] X^T[i][b]  (A = dY^T [out,Bp], B = X^T [in,Bp], fp32 out, colsum = db)
+    //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]     (A = dY [B,out],  B = W^T [in,out], masked, both bf16 layouts)
+    auto wgrad = [&](const u16* dYT, int out_, const u16* XT, int in_, float* dW, float* db) {
+        GemmDescBf d = bdesc(out_, in_, Bp, dYT, Bp, XT, Bp);
+        d.Cf = dW; d.ldcf = in_; d.colsum = db;
+        return d;
+    };
+    auto dgrad = [&](const u16* dY, int out_, int wk, int in_, u16* dX, u16* dXT, const u16* act) {
+        GemmDescBf d = bdesc(B, in_, out_, dY, out_, sc.WbT[wk], out_);
+        d.Cb = dX; d.ldcb = in_; d.CbT = dXT; d.ldt = Bp;
+        if (act) { d.epi = BEPI_MASK; d.mask = act; d.ldmask = in_; }
+        return d;
+    };
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.gyT, D, sc.d2T, H, G[16], G[17]));
+        addb(b, dgrad(sc.gy, D, 8, H, sc.dd2, sc.dd2T, sc.d2));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.dd2T, H, sc.d1T, H, G[14], G[15]));
+        addb(b, dgrad(sc.dd2, H, 7, H, sc.dd1, sc.dd1T, sc.d1));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.dd1T, H, sc.zbT, Z, G[12], G[13]));
+        GemmDescBf gz = bdesc(B, Z, H, sc.dd1, H, sc.WbT[6], H);  // g_z in fp32
+        gz.Cf = sc.gz; gz.ldcf = Z;
+        addb(b, gz);
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
+                                    sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
+                                    eps_in ? nullptr : rng_state, s));
+    {
+        const float* src[2] = {sc.gmu_f, sc.glv_f}; u16* dst[2] = {sc.gmu, sc.glv}; u16* dstT[2] = {sc.gmuT, sc.glvT};
+        int R[2] = {B, B}, C[2] = {Z, Z}, ld[2] = {Z, Z}, ldt[2] = {Bp, Bp};
+        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 2, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.gmuT, Z, sc.h2mT, H, G[4], G[5]));
+        addb(b, wgrad(sc.glvT, Z, sc.h2sT, H, G[10], G[11]));
+        addb(b, dgrad(sc.gmu, Z, 2, H, sc.dh2m, sc.dh2mT, sc.h2m));
+        addb(b, dgrad(sc.glv, Z, 5, H, sc.dh2s, sc.dh2sT, sc.h2s));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.dh2mT, H, sc.h1mT, H, G[2], G[3]));
+        addb(b, wgrad(sc.dh2sT, H, sc.h1sT, H, G[8], G[9]));
+        addb(b, dgrad(sc.dh2m, H, 1, H, sc.dh1m, sc.dh1mT, sc.h1m));
+        addb(b, dgrad(sc.dh2s, H, 4, H, sc.dh1s, sc.dh1sT, sc.h1s));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    {
+        GemmBatchBf b{};
+        addb(b, wgrad(sc.dh1mT, H, sc.xbT, D, G[0], G[1]));
+        addb(b, wgrad(sc.dh1sT, H, sc.xbT, D, G[6], G[7]));
+        RET_IF(launch_gemm_batch_bf16(b, s));
+    }
+    if (has_cond) {
+        const u16* dy[3] = {sc.dh1m, sc.dh1s, sc.dd1};
+        float* gt[3] = {cond->gtab[0], cond->gtab[1], cond->gtab[2]};
+        RET_IF(launch_cond_colsum_bf16(dy, gt, 3, cond->gender, cond->age, B, H, s));
+    }
+    return 0;
+}
+
+}  // extern "C"

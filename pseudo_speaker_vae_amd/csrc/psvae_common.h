@@ -74,6 +74,40 @@ inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda
     return d;
 }
 
+// ---- bf16 path (gemm_bf16.hip): every GEMM is C[m][n] = sum_k A[m][k] B[n][k], bf16 operands ------------
+enum BfEpi { BEPI_NONE = 0, BEPI_RELU = 1, BEPI_MASK = 2, BEPI_RECON = 3 };
+struct GemmDescBf {
+    const unsigned short* A;     // bf16 [M, lda], k contiguous
+    const unsigned short* B;     // bf16 [N, ldb], k contiguous
+    float* Cf;                   // nullable: fp32 output [M, ldcf]
+    unsigned short* Cb;          // nullable: bf16 output [M, ldcb]
+    unsigned short* CbT;         // nullable: bf16 transposed output [N, ldt]
+    const float* bias;           // nullable: fp32 [N]
+    const unsigned short* mask;  // BEPI_MASK: saved bf16 activation [M, ldmask]
+    const float* target;         // BEPI_RECON: fp32 x [M, ldcf]
+    const float* go;             // BEPI_RECON: device scalar (nullable = 1)
+    float* partials;             // BEPI_RECON: one partial sum of squares per tile
+    float* colsum;               // nullable: colsum[m] = sum_k A[m][k]  (bias gradient in the wgrad form)
+    const float* ctab;           // nullable: conditional table [6, N]
+    const int32_t* gender;
+    const int32_t* age;
+    float scale;
+    int M, N, K;                 // K % 32 == 0
+    int lda, ldb, ldcf, ldcb, ldt, ldmask;
+    int epi;
+    int tiles_m, tiles_n, tile_begin;
+};
+struct GemmBatchBf {
+    GemmDescBf d[MAX_GROUP];
+    int n;
+    int total_tiles;
+};
+hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream);
+hipError_t launch_cast_transpose(const float* const* src, unsigned short* const* dst, unsigned short* const* dstT,
+                                 const int* R, const int* C, const int* ld, const int* ldt, int n, hipStream_t s);
+hipError_t launch_cond_colsum_bf16(const unsigned short* const* dY, float* const* gtab, int nprob,
+                                   const int32_t* gender, const int32_t* age, int B, int N, hipStream_t s);
+
 // ---- elementwise / row kernels (elementwise.hip) ------------------------------------------------
 hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 // z = mu + exp(0.5 lv) * eps ; eps from eps_in or Philox; writes eps_out, z

@@ -30,13 +30,18 @@ def _pad(n: int) -> int:
 class FlatLayout:
     """[encoder_mu x6 | encoder_sigma x6 | loss3 | decoder x6] -- decoder last = first bucket to reduce."""
 
-    def __init__(self, shapes: List[torch.Size]):
+    def __init__(self, shapes: List[torch.Size], extra: Optional[List[torch.Size]] = None):
+        """extra: additional tensors (the conditional tables) placed at the end of the encoder bucket"""
         assert len(shapes) == _ffi.NPARAM
         self.shapes = list(shapes)
-        self.offsets = []
+        self.extra_shapes = list(extra or [])
+        self.offsets, self.extra_offsets = [], []
         o = 0
         for i, s in enumerate(shapes):
             if i == 12:
+                for e in self.extra_shapes:
+                    self.extra_offsets.append(o)
+                    o += _pad(e.numel())
                 self.loss_offset = o
                 o += ALIGN
                 self.enc_end = o
@@ -47,12 +52,23 @@ class FlatLayout:
     def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
         return [flat[o:o + s.numel()].view(s) for o, s in zip(self.offsets, self.shapes)]
 
+    def extra_views(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        return [flat[o:o + s.numel()].view(s) for o, s in zip(self.extra_offsets, self.extra_shapes)]
+
 
 class TrainEngine:
     def __init__(self, input_dim: int, latent_dim: int, batch: int, device="cuda:0", seed: int = 0,
                  beta: float = 1.0, normalize_decoder: bool = False, use_cos_loss: bool = False,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 process_group=None, state_dict=None):
+                 process_group=None, state_dict=None, dtype: str = "f32", conditional: bool = False):
+        """dtype "bf16" = BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulate / master weights /
+        gradients); conditional = one-hot gender+age gather tables."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(dtype)
+        if conditional and dtype != "bf16":
+            raise ValueError("the conditional engine path is wired for dtype='bf16' (config 3); "
+                             "fp32 conditioning is available through ConditionalVAEModel")
+        self.dtype, self.conditional = dtype, conditional
         self.D, self.Z, self.B = input_dim, latent_dim, batch
         self.device = torch.device(device)
         self.beta = float(beta)
@@ -72,7 +88,8 @@ class TrainEngine:
             cpu_model.load_state_dict(state_dict)
         src = [p.detach() for p in cpu_model.ordered_params()]
         self.keys = [k for k, _ in cpu_model.named_parameters()]
-        self.layout = FlatLayout([p.shape for p in src])
+        extra = [torch.Size((_ffi.COND_DIM, _ffi.HIDDEN))] * 3 if conditional else None
+        self.layout = FlatLayout([p.shape for p in src], extra)
         n = self.layout.total
         self.flat_params = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -88,8 +105,20 @@ class TrainEngine:
             if process_group is not None else None
         if process_group is not None:
             broadcast_flat(self.flat_params, 0, process_group)
-        self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
-        self.outs = self.ws.new_outputs()
+        self.cond_tabs = self.layout.extra_views(self.flat_params)
+        self.cond_gtabs = self.layout.extra_views(self.flat_grads)
+        for t in self.cond_tabs:  # nn.Linear-like init of the extra one-hot columns (same seed on every rank)
+            bound = 1.0 / (input_dim + _ffi.COND_DIM) ** 0.5
+            t.copy_(torch.empty(t.shape).uniform_(-bound, bound))
+        self.gender = self.age = self._cond = None
+        if dtype == "bf16":
+            if self.flags != 0:
+                raise ValueError("the bf16 path implements the default loss (MSE/10 + beta*KL)")
+            self.ws = ops.Bf16Workspace(batch, input_dim, latent_dim, self.device)
+            self.outs = (self.ws.x_hat, self.ws.mu, self.ws.logvar)
+        else:
+            self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
+            self.outs = self.ws.new_outputs()
         self.step_count = 0
         # device-resident Philox state {seed, offset}: advanced by the forward itself (graph-safe)
         self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
@@ -103,6 +132,14 @@ class TrainEngine:
     def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
+        if self.dtype == "bf16":
+            ops.train_step_bf16(self.ws, x, self.params, self.grads, self.loss3, beta=self.beta, eps=eps,
+                                rng_state=self.rng_state, cond=self._cond)
+            if self.averager is not None:
+                self.averager.reduce_bucket(1)
+                self.averager.reduce_bucket(0)
+                self.averager.wait()
+            return
         if self.flags == 0:  # default loss: the fused 14-launch sequence
             kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
             if self.averager is None:
@@ -128,6 +165,13 @@ class TrainEngine:
                          flags=self.flags, phases=_ffi.PHASE_ENCODER)
         self.averager.reduce_bucket(0)                 # encoder grads + the 3 loss scalars
         self.averager.wait()
+
+    def set_labels(self, gender: torch.Tensor, age: torch.Tensor):
+        """conditional engines: integer labels in {-1,0,1,2} for the current batch (labels.py maps)"""
+        assert self.conditional
+        self.gender = gender.to(device=self.device, dtype=torch.int32).contiguous()
+        self.age = age.to(device=self.device, dtype=torch.int32).contiguous()
+        self._cond = _ffi.make_cond(self.cond_tabs, self.cond_gtabs, self.gender, self.age)
 
     def optimizer_step(self, lr: Optional[float] = None):
         """fused Adam over the flat buffers (lightning.py:205)."""
@@ -160,3 +204,35 @@ class TrainEngine:
 
     def replay(self):
         self._graph.replay()
+
+    def capture_ddp(self, x: torch.Tensor):
+        """Data-parallel variant: the step cannot be ONE graph (the RCCL all-reduces stay eager), so capture
+        its two halves -- [forward + ELBO + decoder backward] and [encoder backward] -- and replay them around
+        the collectives: graph A, all-reduce(decoder bucket) on RCCL's stream, graph B underneath it,
+        all-reduce(encoder bucket + loss scalars), wait.  Host cost per step: two graph launches + two
+        collective calls instead of ~14 kernel launches."""
+        if self.averager is None or self.flags != 0:
+            raise _ffi.PsvaeError("capture_ddp needs a process group and the default loss")
+        self.static_x = x.detach().clone()
+        kw = dict(beta=self.beta, rng_state=self.rng_state)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3, **kw)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._ga, self._gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._ga):
+            ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
+                           phases=_ffi.PHASE_DECODER, **kw)
+        with torch.cuda.graph(self._gb, pool=self._ga.pool()):
+            ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
+                           phases=_ffi.PHASE_ENCODER, **kw)
+
+    def replay_ddp(self):
+        self._ga.replay()
+        self.averager.reduce_bucket(1)
+        self._gb.replay()
+        self.averager.reduce_bucket(0)
+        self.averager.wait()

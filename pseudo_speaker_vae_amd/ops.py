@@ -130,6 +130,32 @@ def train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence
         _ffi.ptr(loss3), _ffi.ptr(ws.scratch), phases, _ffi.stream_ptr()), "train_step")
 
 
+class Bf16Workspace:
+    """buffers of one batch shape for the bf16 training pass (scratch is zero-filled once: see psvae.h)"""
+
+    def __init__(self, B: int, D: int, Z: int, device):
+        self.B, self.D, self.Z = B, D, Z
+        self.dims = _ffi.Dims(B, D, Z)
+        nbytes = int(_ffi.lib().psvae_bf16_scratch_bytes(C.byref(self.dims)))
+        self.scratch = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.eps, self.z = f(B, Z), f(B, Z)
+        self.x_hat, self.mu, self.logvar = f(B, D), f(B, Z), f(B, Z)
+
+
+def train_step_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], loss3,
+                    beta: float = 1.0, eps: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
+                    rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None, cond=None):
+    """one training pass with bf16 MFMA operands (config 3): psvae_train_step_bf16"""
+    P = _ffi.make_params(params)
+    G = _ffi.make_grads(grads)
+    _ffi.check(_ffi.lib().psvae_train_step_bf16(
+        C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None,
+        _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat),
+        _ffi.ptr(ws.mu), _ffi.ptr(ws.logvar), beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3),
+        _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "train_step_bf16")
+
+
 def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
            cond_tab=None, gender=None, age=None, out: Optional[torch.Tensor] = None,
            scratch: Optional[torch.Tensor] = None) -> torch.Tensor:

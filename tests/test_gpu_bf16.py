@@ -1,0 +1,79 @@
+"""bf16 training pass (BASELINE config 3) against the oracle's bf16 emulation (same rounding points).
+The reference has no bf16 or conditional code: parity for this path is unpinned by the reference."""
+import pytest
+import torch
+
+from helpers import assert_close, rel_err
+from oracle import psvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# bf16 keeps 8 significant bits (ulp 2^-8 = 3.9e-3 relative).  The HIP path and the emulation round at the
+# same points, but fp32 sums that differ in the last bit can round to different bf16 neighbours.
+BF16_TOL = 6e-3
+
+
+def assert_close_bf16(a, b, what):
+    """gradients: a ReLU-mask or bf16-neighbour flip moves one row of dW by O(1/sqrt(B)), so the bound is on
+    the relative L2 error of the whole tensor, with a loose cap on the worst element"""
+    a, b = a.double(), b.double()
+    l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert l2 <= 1e-2, f"{what}: relative L2 error {l2:.3e}"
+    assert rel_err(a, b) <= 6e-2, f"{what}: worst element {rel_err(a, b):.3e}"
+
+
+@pytest.mark.parametrize("D,Z,B,cond", [(256, 64, 4096, True), (256, 64, 1024, False), (256, 64, 100, True),
+                                        (512, 128, 64, False)])
+def test_bf16_train_step_matches_emulation(D, Z, B, cond):
+    from pseudo_speaker_vae_amd import _ffi, ops
+    p = O.init_params(D, Z, 1)
+    torch.manual_seed(B)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    tabs = gender = age = None
+    c = None
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    keep = []
+    if cond:
+        tabs = {k: torch.randn(O.COND_DIM, O.HIDDEN) * 0.05 for k in O.COND_KEYS}
+        gender = torch.randint(-1, 3, (B,), dtype=torch.int32)
+        age = torch.randint(-1, 3, (B,), dtype=torch.int32)
+        tabd = [tabs[k].to(DEV) for k in O.COND_KEYS]
+        gtab = [torch.full_like(t, float("nan")) for t in tabd]
+        gd, ad = gender.to(DEV), age.to(DEV)
+        keep = [tabd, gtab, gd, ad]
+        c = _ffi.make_cond(tabd, gtab, gd, ad)
+    ws = ops.Bf16Workspace(B, D, Z, DEV)
+    grads = [torch.full_like(t, float("nan")) for t in params]
+    loss3 = torch.full((3,), float("nan"), device=DEV)
+    go = 0.9
+    ops.train_step_bf16(ws, x.to(DEV), params, grads, loss3, beta=0.7, eps=eps.to(DEV),
+                        grad_loss=torch.tensor([go], device=DEV), cond=c)
+    torch.cuda.synchronize()
+    losses, ref, outs, tg = O.train_step_bf16(p, x, eps, 0.7, go, tabs, gender, age)
+    assert_close(ws.x_hat.cpu(), outs["x_hat"], BF16_TOL, "x_hat")
+    assert_close(ws.mu.cpu(), outs["mu"], BF16_TOL, "mu")
+    assert_close(ws.logvar.cpu(), outs["logvar"], BF16_TOL, "logvar")
+    for i, k in enumerate(("total", "recon", "kl")):
+        assert abs(float(loss3[i]) - float(losses[k])) <= BF16_TOL * max(1.0, abs(float(losses[k]))), k
+    for k, g in zip(O.PARAM_KEYS, grads):
+        assert torch.isfinite(g).all(), k
+        assert_close_bf16(g.cpu(), ref[k], "grad " + k)
+    if cond:
+        for k, g in zip(O.COND_KEYS, keep[1]):
+            assert_close_bf16(g.cpu(), tg[k], "grad " + k)
+    # and the bf16 path stays close to the fp32 oracle (sanity of the emulation itself)
+    if not cond:
+        f32_losses, f32_grads, _, _ = O.train_step(p, x, eps, 0.7, go=go)
+        assert abs(float(loss3[0]) - float(f32_losses["total"])) < 2e-2
+        assert rel_err(grads[16].cpu(), f32_grads["decoder.4.weight"]) < 5e-2
+
+
+def test_bf16_rejects_unsupported_dims():
+    from pseudo_speaker_vae_amd import _ffi, ops
+    with pytest.raises(_ffi.PsvaeError):
+        D, Z, B = 784, 20, 8
+        p = O.init_params(D, Z, 0)
+        params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+        ws = ops.Bf16Workspace(B, D, Z, DEV)
+        ops.train_step_bf16(ws, torch.randn(B, D, device=DEV), params, [torch.empty_like(t) for t in params],
+                            torch.empty(3, device=DEV))
