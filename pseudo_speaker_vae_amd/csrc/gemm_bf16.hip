@@ -18,6 +18,7 @@ namespace psvae {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define PSVAE_GLOBAL __attribute__((address_space(1)))
 template <typename V, typename P>
@@ -186,10 +187,18 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             if (epi == BEPI_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (epi == BEPI_MASK) {  // ReLU backward: mask = saved bf16 activation [M, ldcb]
+            } else if (epi == BEPI_MASK) {  // ReLU backward: mask = saved bf16 activation [M, ldmask]
+                const u16* mp = d.mask + (size_t)row * d.ldmask + col;
+                if (colfull && ((d.ldmask & 3) == 0)) {
+                    const u32x2 mk = ldgb<u32x2>(mp);  // 4 bf16
+                    const u16 m4[4] = {(u16)(mk.x & 0xffff), (u16)(mk.x >> 16), (u16)(mk.y & 0xffff), (u16)(mk.y >> 16)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < N) v[e] = bf2f(ldgb<u16>(d.mask + (size_t)row * d.ldmask + col + e)) > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = bf2f(m4[e]) > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) v[e] = bf2f(ldgb<u16>(mp + e)) > 0.f ? v[e] : 0.f;
+                }
             }
             if (d.Cf) {  // fp32 output (final outputs, wgrads)
                 float* p = d.Cf + (size_t)row * d.ldcf + col;
@@ -211,9 +220,16 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             }
             if (d.Cb) {
                 u16* p = d.Cb + (size_t)row * d.ldcb + col;
+                if (colfull && ((d.ldcb & 3) == 0)) {  // 4 bf16 = one 8-byte store
+                    u32x2 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    stgb<u32x2>(p, pk);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < N) stgb<u16>(p + e, f2bf(v[e]));
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) stgb<u16>(p + e, f2bf(v[e]));
+                }
             }
         } else {
             v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -227,9 +243,17 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             const int n = i / MQ, mq = i % MQ;
             const int gn = n0 + n, gm = m0 + 4 * mq;
             if (gn >= N) continue;
+            u16* p = d.CbT + (size_t)gn * d.ldt + gm;
+            if (gm + 3 < M && ((d.ldt & 3) == 0)) {
+                u32x2 pk;
+                pk.x = (unsigned)f2bf(smem[(4 * mq + 0) * SC + n]) | ((unsigned)f2bf(smem[(4 * mq + 1) * SC + n]) << 16);
+                pk.y = (unsigned)f2bf(smem[(4 * mq + 2) * SC + n]) | ((unsigned)f2bf(smem[(4 * mq + 3) * SC + n]) << 16);
+                stgb<u32x2>(p, pk);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (gm + e < M) stgb<u16>(d.CbT + (size_t)gn * d.ldt + gm + e, f2bf(smem[(4 * mq + e) * SC + n]));
+                for (int e = 0; e < 4; ++e)
+                    if (gm + e < M) stgb<u16>(p + e, f2bf(smem[(4 * mq + e) * SC + n]));
+            }
         }
     }
     if (epi == BEPI_RECON) {
@@ -290,14 +314,14 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
     long t44 = 0, t22 = 0;
-    int kmin = 1 << 30;
+    int kmax = 0;
     for (int i = 0; i < b.n; ++i) {
         t44 += (long)((b.d[i].M + 63) / 64) * ((b.d[i].N + 63) / 64);
         t22 += (long)((b.d[i].M + 31) / 32) * ((b.d[i].N + 31) / 32);
-        kmin = b.d[i].K < kmin ? b.d[i].K : kmin;
+        kmax = b.d[i].K > kmax ? b.d[i].K : kmax;
     }
     if (t44 >= 192) {
-        if (t44 >= 1024 && kmin <= 1024) return launch_bf<4, 4, 2, 2, 1, 2>(b, stream);  // 128x128 tiles, no split
+        if (t44 >= 2048 && kmax <= 1024) return launch_bf<4, 4, 2, 2, 1, 2>(b, stream);  // 128x128 tiles, no split
         return launch_bf<4, 4, 1, 1, 4, 2>(b, stream);                                    // 64x64, k split 4
     }
     if (t22 >= 128) return launch_bf<2, 2, 1, 1, 4, 4>(b, stream);                         // 32x32, k split 4
@@ -355,6 +379,24 @@ hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* 
     }
     a.n = n;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(t), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// one-hot matrix of the labels, transposed: ohT[c][b] (bf16 0/1), c < 6, b < Bp (padding columns zero).
+// With it the conditional-table gradient  gtab[c][n] = sum_b onehot[b][c] dY[b][n]  is one more wgrad GEMM.
+__global__ __launch_bounds__(256) void onehot_t_kernel(const int32_t* __restrict__ gender, const int32_t* __restrict__ age,
+                                                       u16* __restrict__ ohT, int B, int Bp) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= Bp) return;
+    const int g = b < B ? gender[b] : -1, a = b < B ? age[b] : -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ohT[(size_t)c * Bp + b] = (g == c) ? (u16)0x3F80 : (u16)0;
+        ohT[(size_t)(3 + c) * Bp + b] = (a == c) ? (u16)0x3F80 : (u16)0;
+    }
+}
+hipError_t launch_onehot_t(const int32_t* gender, const int32_t* age, u16* ohT, int B, int Bp, hipStream_t s) {
+    hipLaunchKernelGGL(onehot_t_kernel, dim3((Bp + 255) / 256), dim3(256), 0, s, gender, age, ohT, B, Bp);
     return hipGetLastError();
 }
 

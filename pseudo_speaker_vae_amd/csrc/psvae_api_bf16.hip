@@ -25,6 +25,7 @@ struct BfScratch {
     u16 *gy, *gyT;                                  // [B,D], [D,Bp]
     u16 *dd2, *dd2T, *dd1, *dd1T, *dh2m, *dh2mT, *dh2s, *dh2sT, *dh1m, *dh1mT, *dh1s, *dh1sT;  // [B,H] / [H,Bp]
     u16 *gmu, *gmuT, *glv, *glvT;                   // [B,Z] / [Z,Bp]
+    u16* ohT;                                       // [6,Bp] one-hot labels, transposed
     float *gz, *gmu_f, *glv_f, *kl_partials, *recon_partials;
     int n_recon_max;
     size_t bytes;
@@ -61,6 +62,7 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
     s.zb = tb(B * Z); s.zbT = tb(Z * Bp);
     s.gy = tb(B * D); s.gyT = tb(D * Bp);
     s.gmu = tb(B * Z); s.gmuT = tb(Z * Bp); s.glv = tb(B * Z); s.glvT = tb(Z * Bp);
+    s.ohT = tb(8 * Bp);
     s.gz = tf(B * Z); s.gmu_f = tf(B * Z); s.glv_f = tf(B * Z);
     s.kl_partials = tf((size_t)reparam_blocks(B * Z));
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));
@@ -112,6 +114,7 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     int wo[9], wi[9];
     weight_dims(D, Z, wo, wi);
 
+    if (has_cond) RET_IF(launch_onehot_t(cond->gender, cond->age, sc.ohT, B, Bp, s));
     {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
@@ -205,6 +208,7 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     {
         GemmBatchBf b{};
         addb(b, wgrad(sc.dd1T, H, sc.zbT, Z, G[12], G[13]));
+        if (has_cond) addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dd1T, H, cond->gtab[2], nullptr));  // table grad
         GemmDescBf gz = bdesc(B, Z, H, sc.dd1, H, sc.WbT[6], H);  // g_z in fp32
         gz.Cf = sc.gz; gz.ldcf = Z;
         addb(b, gz);
@@ -238,12 +242,11 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
         GemmBatchBf b{};
         addb(b, wgrad(sc.dh1mT, H, sc.xbT, D, G[0], G[1]));
         addb(b, wgrad(sc.dh1sT, H, sc.xbT, D, G[6], G[7]));
+        if (has_cond) {  // gtab[c][n] = sum_b onehot[b][c] dh1[b][n]: two more wgrad problems in this launch
+            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1mT, H, cond->gtab[0], nullptr));
+            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1sT, H, cond->gtab[1], nullptr));
+        }
         RET_IF(launch_gemm_batch_bf16(b, s));
-    }
-    if (has_cond) {
-        const u16* dy[3] = {sc.dh1m, sc.dh1s, sc.dd1};
-        float* gt[3] = {cond->gtab[0], cond->gtab[1], cond->gtab[2]};
-        RET_IF(launch_cond_colsum_bf16(dy, gt, 3, cond->gender, cond->age, B, H, s));
     }
     return 0;
 }
