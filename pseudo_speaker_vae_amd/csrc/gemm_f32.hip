@@ -451,7 +451,11 @@ void finalize_batch(GemmBatch& b, int cfg) {
         tot += flops[i];
     }
     int pick_tn = cfg, pick_other = cfg;
-    if (cfg == 0) {
+    static const int force_tn = env_int("PSVAE_CFG_TN", 0), force_other = env_int("PSVAE_CFG_OTHER", 0);  // tuning
+    if (cfg == 0 && force_tn && force_other) {
+        pick_tn = force_tn;
+        pick_other = force_other;
+    } else if (cfg == 0) {
         // each class gets its FLOP share of the 256 CUs (at least 32: small problems ride in the
         // others' tails); within a class the slowest problem decides
         for (int cls = 0; cls < 2; ++cls) {
