@@ -181,8 +181,8 @@ def main():
     mode = args.mode
     if mode == "auto":
         mode = "graph"
-    if mode == "graph" and pg is not None:
-        mode = "graph-ddp"  # two captured halves around the eager RCCL all-reduces
+    if mode == "graph" and pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
+        mode = "graph-ddp-overlap"  # two captured halves around two RCCL all-reduces (decoder bucket overlapped)
         eng.capture_ddp(x)
 
         def step():
@@ -190,6 +190,8 @@ def main():
             if args.with_adam:
                 eng.optimizer_step()
     elif mode == "graph":
+        if pg is not None:
+            mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
         eng.capture(x)
 
         def step():

@@ -38,6 +38,17 @@ class GradAverager:
             self._needs_scale.append(i)
         self._pending.append(w)
 
+    def reduce_all(self):
+        """one collective over the whole flat buffer (fewer stream hand-offs than per-bucket overlap)"""
+        if not dist.is_initialized():
+            return
+        if self.backend == "nccl":
+            w = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:
+            w = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._needs_scale = list(range(len(self.buckets)))
+        self._pending.append(w)
+
     def wait(self):
         """make the current stream (or the host, for gloo) wait for every started bucket"""
         for w in self._pending:

@@ -129,20 +129,19 @@ class TrainEngine:
     def state_dict(self):
         return {k: p.detach().clone() for k, p in zip(self.keys, self.params)}
 
-    def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+    def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):
         """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
         if self.dtype == "bf16":
             ops.train_step_bf16(self.ws, x, self.params, self.grads, self.loss3, beta=self.beta, eps=eps,
                                 rng_state=self.rng_state, cond=self._cond)
-            if self.averager is not None:
-                self.averager.reduce_bucket(1)
-                self.averager.reduce_bucket(0)
+            if self.averager is not None and not _local_only:
+                self.averager.reduce_all()
                 self.averager.wait()
             return
         if self.flags == 0:  # default loss: the fused 14-launch sequence
             kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
-            if self.averager is None:
+            if self.averager is None or _local_only:
                 ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
                 return
             ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
@@ -154,7 +153,7 @@ class TrainEngine:
         xh, mu, lv = ops.vae_forward(self.ws, x, self.params, eps, 0, 0, self.flags, outs=self.outs,
                                      rng_state=self.rng_state)
         ops.elbo(self.ws, x, xh, mu, lv, self.beta, self.flags, self.loss3)
-        if self.averager is None:
+        if self.averager is None or _local_only:
             ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
                              flags=self.flags)
             return
@@ -186,24 +185,27 @@ class TrainEngine:
         ~20 kernels of a few microseconds each).  The captured step reads its batch from a static
         buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which
         the graph itself advances, so every replay draws fresh noise."""
-        if self.averager is not None:
-            raise _ffi.PsvaeError("graph capture is for the single-GPU path; RCCL collectives stay eager")
         self.static_x = x.detach().clone()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up outside capture (hipFuncSetAttribute, lazy module load)
-                self.forward_backward(self.static_x)
+                self.forward_backward(self.static_x, _local_only=True)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.forward_backward(self.static_x)
+            self.forward_backward(self.static_x, _local_only=True)
         self._graph = g
         return g
 
     def replay(self):
+        """one captured step; with a process group: followed by ONE all-reduce of the flat gradient buffer
+        (the collective itself stays outside the graph)"""
         self._graph.replay()
+        if self.averager is not None:
+            self.averager.reduce_all()
+            self.averager.wait()
 
     def capture_ddp(self, x: torch.Tensor):
         """Data-parallel variant: the step cannot be ONE graph (the RCCL all-reduces stay eager), so capture
