@@ -168,6 +168,12 @@ int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, in
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask,
                    float* colsum, int epi, int tile, void* stream);
 
+/* Batch assembly from a packed embedding table resident in HBM: out[b,:] = table[idx[b],:] (an
+ * out-of-range index gives a zero row).  Stands in for the per-sample torch.load of
+ * ps_vae/data/cv.py:58-76 / vctk.py:51-67 (one tiny file per embedding). */
+int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_t* idx, int64_t B, float* out,
+                          void* stream);
+
 /* Fused multi-tensor Adam on flat buffers (lightning.py:205; torch.optim.Adam semantics).
  * grad_scale multiplies the gradient first (1/world_size after an all-reduce(sum)).  Hyper-parameters
  * are doubles so that 1-beta etc. round exactly as torch's (python-float) arithmetic does. */

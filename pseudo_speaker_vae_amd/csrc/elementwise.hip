@@ -502,4 +502,39 @@ hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int np
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// packed embedding table -> batch (replaces one torch.load per sample, data/cv.py:58-76):
+// out[b, :] = table[idx[b], :]; whole rows, 16 B per lane, one wavefront per row; an out-of-range
+// index yields a zero row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t N, int D,
+                                                          const int64_t* __restrict__ idx, int64_t B,
+                                                          float* __restrict__ out, int vec_ok) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wpb = blockDim.x >> 6;
+    for (int64_t b = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * wpb) {
+        const int64_t r = idx[b];
+        const bool ok = r >= 0 && r < N;
+        const float* __restrict__ src = table + (size_t)(ok ? r : 0) * D;
+        float* __restrict__ dst = out + (size_t)b * D;
+        if (vec_ok) {
+            for (int d = 4 * lane; d < D; d += 256) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(src + d);
+                *reinterpret_cast<f32x4*>(dst + d) = v;
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) dst[d] = ok ? src[d] : 0.f;
+        }
+    }
+}
+
+hipError_t launch_gather_rows(const float* table, int64_t N, int D, const int64_t* idx, int64_t B, float* out,
+                              hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int vec_ok = ((D & 3) == 0) && al16(table) && al16(out);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, 4)), dim3(256), 0, s, table, N, D, idx, B, out, vec_ok);
+    return hipGetLastError();
+}
+
 }  // namespace psvae

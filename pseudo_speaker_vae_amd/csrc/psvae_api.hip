@@ -450,6 +450,14 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
     return 0;
 }
 
+int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_t* idx, int64_t B, float* out,
+                          void* stream) {
+    if (!table || !idx || !out) return PSVAE_ERR_NULL;
+    if (N <= 0 || D <= 0 || B < 0 || D > (1 << 20)) return PSVAE_ERR_SHAPE;
+    RET_IF(launch_gather_rows(table, N, (int)D, idx, B, out, (hipStream_t)stream));
+    return 0;
+}
+
 int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                         double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                         void* stream) {

@@ -41,6 +41,12 @@ def _worker(rank, world, port, q):
         av.reduce_bucket(0)
         av.wait()
         ok1 = bool(torch.allclose(flat, torch.full_like(flat, (1 + world) / 2)))
+        # the default path: ONE collective over the whole flat buffer
+        flat1 = torch.full((lay.total,), float(10 * (rank + 1)))
+        av1 = GradAverager(flat1, [0, lay.enc_end, lay.total])
+        av1.reduce_all()
+        av1.wait()
+        ok1 = ok1 and bool(torch.allclose(flat1, torch.full_like(flat1, 10 * (1 + world) / 2)))
         # parameter broadcast from rank 0
         pflat = torch.full((8,), float(rank))
         broadcast_flat(pflat, 0)

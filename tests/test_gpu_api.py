@@ -230,3 +230,25 @@ def test_conditional_model_matches_concat_definition():
     m2.from_concat_state_dict(p_cat)
     for (k, v), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k == k2 and torch.equal(v.cpu(), v2), k
+
+
+def test_packed_embedding_table_gather():
+    from pseudo_speaker_vae_amd.data import PackedEmbeddingTable
+    torch.manual_seed(0)
+    N, D = 1000, 256
+    emb = torch.randn(N, D)
+    gender = torch.randint(-1, 3, (N,))
+    t = PackedEmbeddingTable.from_samples([e.view(1, D, 1) for e in emb], {"gender": gender}, DEV)
+    idx = torch.tensor([0, 999, 5, 5, 1000, -1, 37])
+    out = t.batch(idx).cpu()
+    assert torch.equal(out[:4], emb[[0, 999, 5, 5]]) and torch.equal(out[6], emb[37])
+    assert (out[4] == 0).all() and (out[5] == 0).all()          # out-of-range index -> zero row
+    seen = []
+    for x, lab in t.epoch(128, generator=torch.Generator().manual_seed(1)):
+        assert x.shape[1] == D and lab["gender"].shape[0] == x.shape[0]
+        seen.append(x.cpu())
+    allx = torch.cat(seen)
+    assert allx.shape == (N, D)
+    assert torch.equal(allx.sum(0), emb[torch.randperm(N, generator=torch.Generator().manual_seed(1))].sum(0))
+    odd = PackedEmbeddingTable(torch.randn(10, 30), device=DEV)  # D % 4 != 0: scalar path
+    assert torch.equal(odd.batch(torch.tensor([3, 9])).cpu(), odd.table[[3, 9]].cpu())
