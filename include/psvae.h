@@ -168,6 +168,17 @@ int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, in
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask,
                    float* colsum, int epi, int tile, void* stream);
 
+/* Fused Langevin conditional sampler: the loop of conditional_synthesis (ps_vae/inference.py:72-103) for a
+ * single-label ReLU LatentClassifier with one hidden layer (hidden = its width <= 128, W1[hidden,Z], W2[C,hidden];
+ * latent_classifier.py:30-40) or a single Linear (hidden = 0, W1[C,Z]).  z[N,Z] is updated in place over
+ * num_steps steps:  z += 0.5 s^2 grad(log p(y=target|z) - 0.5|z|^2) + s w noise.  noises (nullable, [T,N,Z])
+ * injects the per-step normals (parity tests), else they come from Philox(seed, offset + t*ceil(N*Z/4) + ..);
+ * history (nullable, [T,N,Z]) receives z after every step.  Z in {16,32,64,128}, C <= 8. */
+int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const float* W1, const float* b1,
+                       const float* W2, const float* b2, float* z, int32_t target, float step_size,
+                       float noise_weight, int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
+                       float* history, void* stream);
+
 /* Batch assembly from a packed embedding table resident in HBM: out[b,:] = table[idx[b],:] (an
  * out-of-range index gives a zero row).  Stands in for the per-sample torch.load of
  * ps_vae/data/cv.py:58-76 / vctk.py:51-67 (one tiny file per embedding). */

@@ -450,6 +450,23 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
     return 0;
 }
 
+int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const float* W1, const float* b1,
+                       const float* W2, const float* b2, float* z, int32_t target, float step_size, float noise_weight,
+                       int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
+                       void* stream) {
+    if (!W1 || !b1 || !z) return PSVAE_ERR_NULL;
+    if (hidden > 0 && (!W2 || !b2)) return PSVAE_ERR_NULL;
+    if (N <= 0 || num_steps < 0 || C <= 0 || C > 8 || hidden < 0 || hidden > 128) return PSVAE_ERR_SHAPE;
+    if (!(Z == 16 || Z == 32 || Z == 64 || Z == 128)) return PSVAE_ERR_SHAPE;
+    if (target < 0 || target >= C) return PSVAE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(noises) & 15) ||
+        (reinterpret_cast<uintptr_t>(history) & 15))
+        return PSVAE_ERR_ALIGN;
+    RET_IF(launch_langevin(N, (int)Z, (int)hidden, (int)C, W1, b1, W2, b2, z, target, step_size, noise_weight,
+                           num_steps, noises, seed, offset, history, (hipStream_t)stream));
+    return 0;
+}
+
 int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_t* idx, int64_t B, float* out,
                           void* stream) {
     if (!table || !idx || !out) return PSVAE_ERR_NULL;

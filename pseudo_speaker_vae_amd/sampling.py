@@ -11,7 +11,9 @@ from typing import Optional, Union
 import torch
 import torch.nn.functional as F
 
-from . import ops
+import torch.nn as nn
+
+from . import _ffi, ops
 
 
 def _latent_dim(vae_model) -> int:
@@ -38,12 +40,60 @@ def _log_p_y_given_z(logits, target):
     return log_probs[:, target]
 
 
+def _fusable_classifier(clf, target):
+    """(W1, b1, W2, b2, hidden, C) if the classifier is what the fused kernel covers: single label, ReLU,
+    one or two Linear layers (latent_classifier.py:30-40), hidden <= 128, C <= 8; else None."""
+    if clf is None or not getattr(clf, "single_label_mode", False) or not isinstance(target, int):
+        return None
+    mods = list(clf.layers)
+    lins = [m for m in mods if isinstance(m, nn.Linear)]
+    acts = [m for m in mods if not isinstance(m, nn.Linear)]
+    if len(lins) not in (1, 2) or any(not isinstance(a, nn.ReLU) for a in acts):
+        return None
+    C = lins[-1].out_features
+    hidden = lins[0].out_features if len(lins) == 2 else 0
+    if C > 8 or hidden > 128 or lins[0].in_features not in (16, 32, 64, 128) or not (0 <= target < C):
+        return None
+    w = [p.detach().float().contiguous() for l in lins for p in (l.weight, l.bias)]
+    return (w[0], w[1], w[2] if hidden else None, w[3] if hidden else None, hidden, C)
+
+
+def langevin_fused(clf_params, z: torch.Tensor, target: int, step_size: float, noise_weight: float, num_steps: int,
+                   noises=None, seed: int = 0, offset: int = 0, return_history: bool = False):
+    """psvae_langevin_f32: all `num_steps` updates of z[N,Z] in one kernel, no host round trips"""
+    W1, b1, W2, b2, hidden, C = clf_params
+    z = z.detach().float().contiguous().clone()
+    N, Z = z.shape
+    hist = torch.empty(num_steps, N, Z, dtype=torch.float32, device=z.device) if return_history else None
+    nz = None if noises is None else noises.to(device=z.device, dtype=torch.float32).contiguous()
+    _ffi.check(_ffi.lib().psvae_langevin_f32(N, Z, hidden, C, _ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(W2), _ffi.ptr(b2),
+                                             _ffi.ptr(z), int(target), float(step_size), float(noise_weight),
+                                             int(num_steps), _ffi.ptr(nz), seed, offset, _ffi.ptr(hist),
+                                             _ffi.stream_ptr()), "langevin")
+    return z, hist
+
+
 def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[int, dict], step_size: float = 0.01,
                           num_steps: int = 100, noise_weight: float = 1.0, return_history: bool = False,
                           device: str = "cuda", z0: Optional[torch.Tensor] = None, noises=None):
     """inference.py:29-110.  `z0` / `noises` (optional) inject the initial point and the per-step
     noise (parity tests); by default both come from torch's generator on `device`."""
     dim = _latent_dim(vae_model)
+    fus = _fusable_classifier(getattr(vae_model, "classifier", None), classifier_target)
+    if fus is not None and torch.device(device).type == "cuda":
+        # fused HIP path: z0 and the noise from the device Philox stream (seeded by torch.manual_seed)
+        seed = torch.initial_seed() & ((1 << 64) - 1)
+        nblk = (num_samples * dim + 3) // 4
+        z_init = ops.philox_normal(num_samples * dim, seed, 0, device).view(num_samples, dim) if z0 is None else z0.to(device)
+        z, hist = langevin_fused(fus, z_init, classifier_target, step_size, noise_weight, num_steps, noises,
+                                 seed=seed, offset=nblk, return_history=return_history)
+        with torch.no_grad():
+            x_hat = vae_model.decode(z).detach().cpu()
+        if return_history:
+            return x_hat, list(hist.cpu().numpy())
+        return x_hat
+    # general path (multi-label heads, other activations, deeper classifiers): the reference's loop on the
+    # device with torch ops, still without per-step host synchronisation
     z = (torch.randn((num_samples, dim), device=device) if z0 is None else z0.to(device)).requires_grad_()
     history = []
     for t in range(num_steps):
