@@ -503,6 +503,55 @@ hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int np
 }
 
 // ---------------------------------------------------------------------------------------------
+// grouped fp32 transposes: dst[i] [C,R] = src[i] [R,C]^T (32x32 LDS tiles, whole 128-B rows both ways).
+// The forward wants the weights k-MAJOR ([in,out]): a k-contiguous weight operand is read in 64-B pieces
+// (half of every 128-B line), which halves the per-CU feed rate of the register-direct GEMM.
+// ---------------------------------------------------------------------------------------------
+struct TransposeArgs {
+    const float* src[9];
+    float* dst[9];
+    int R[9], Cc[9], tile_begin[9];
+    int n;
+};
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const TransposeArgs a) {
+    __shared__ float tile[32][33];
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.tile_begin[i]) pi = i;
+    const int R = a.R[pi], Cc = a.Cc[pi];
+    const int tiles_c = (Cc + 31) / 32;
+    const int lt = blockIdx.x - a.tile_begin[pi];
+    const int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 32;
+    const float* __restrict__ src = a.src[pi];
+    float* __restrict__ dst = a.dst[pi];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        tile[ty + 8 * i][tx] = (rr < R && cc < Cc) ? src[(size_t)rr * Cc + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+        if (cc < Cc && rr < R) dst[(size_t)cc * R + rr] = tile[tx][ty + 8 * i];
+    }
+}
+hipError_t launch_transpose_f32(const float* const* src, float* const* dst, const int* R, const int* Cc, int n,
+                                hipStream_t s) {
+    TransposeArgs a{};
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.R[i] = R[i]; a.Cc[i] = Cc[i];
+        a.tile_begin[i] = t;
+        t += ((R[i] + 31) / 32) * ((Cc[i] + 31) / 32);
+    }
+    a.n = n;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3(t), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // packed embedding table -> batch (replaces one torch.load per sample, data/cv.py:58-76):
 // out[b, :] = table[idx[b], :]; whole rows, 16 B per lane, one wavefront per row; an out-of-range
 // index yields a zero row.

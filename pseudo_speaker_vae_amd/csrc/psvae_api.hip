@@ -22,6 +22,7 @@ int check_dims(const psvae_dims* d) {
 // scratch carve (floats), identical for every call so phases can share it
 struct Scratch {
     float *y, *gy, *dd2, *dd1, *gz, *gmu, *glv, *dh2m, *dh2s, *dh1m, *dh1s, *partials, *kl_partials, *recon_partials;
+    float* wt[9];  // k-major ([in,out]) copies of the 9 weight matrices for the fused step's forward
     int n_recon_max;
     size_t bytes;
 };
@@ -49,6 +50,10 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
     s.kl_partials = take((size_t)reparam_blocks(B * Z));
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));  // smallest GEMM tile is 16 x 32
     s.recon_partials = take((size_t)s.n_recon_max);
+    {
+        const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
+        for (int k = 0; k < 9; ++k) s.wt[k] = take((size_t)(o[k] * in[k]));
+    }
     s.bytes = off;
     return s;
 }
@@ -309,41 +314,54 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     Scratch sc = carve(scratch, B, D, Z);
     const int n_kl = reparam_blocks((int64_t)B * Z);
 
+    static const bool kmajor_w = getenv("PSVAE_FWD_NT") == nullptr;  // default: forward reads k-major weight copies
+    // forward Linear l:  Y = X W^T.  With the k-major copy WT[in,out] it is the NN product X * WT, whose weight
+    // operand is read in whole 128-B lines (the k-contiguous W[out,in] is read in half lines).
+    auto fwd = [&](const float* X, int K, int wk, int N, float* Y, int epi) {
+        return kmajor_w ? make_desc(GK_NN, B, N, K, X, K, sc.wt[wk], N, Y, N, epi, P[2 * wk + 1])
+                        : make_desc(GK_NT, B, N, K, X, K, P[2 * wk], K, Y, N, epi, P[2 * wk + 1]);
+    };
     if (phases & PSVAE_PHASE_DECODER) {
+        if (kmajor_w) {
+            const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
+            const float* src[9]; int R[9], C[9];
+            for (int k = 0; k < 9; ++k) { src[k] = P[2 * k]; R[k] = (int)o[k]; C[k] = (int)in[k]; }
+            RET_IF(launch_transpose_f32(src, sc.wt, R, C, 9, s));
+        }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_NT, B, H, D, x, D, P[0], D, acts->h1m, H, EPI_BIAS_RELU, P[1]));
-            add(b, make_desc(GK_NT, B, H, D, x, D, P[6], D, acts->h1s, H, EPI_BIAS_RELU, P[7]));
+            add(b, fwd(x, D, 0, H, acts->h1m, EPI_BIAS_RELU));
+            add(b, fwd(x, D, 3, H, acts->h1s, EPI_BIAS_RELU));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_NT, B, H, H, acts->h1m, H, P[2], H, acts->h2m, H, EPI_BIAS_RELU, P[3]));
-            add(b, make_desc(GK_NT, B, H, H, acts->h1s, H, P[8], H, acts->h2s, H, EPI_BIAS_RELU, P[9]));
+            add(b, fwd(acts->h1m, H, 1, H, acts->h2m, EPI_BIAS_RELU));
+            add(b, fwd(acts->h1s, H, 4, H, acts->h2s, EPI_BIAS_RELU));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_NT, B, Z, H, acts->h2m, H, P[4], H, mu, Z, EPI_BIAS, P[5]));
-            add(b, make_desc(GK_NT, B, Z, H, acts->h2s, H, P[10], H, logvar, Z, EPI_BIAS, P[11]));
+            add(b, fwd(acts->h2m, H, 2, Z, mu, EPI_BIAS));
+            add(b, fwd(acts->h2s, H, 5, Z, logvar, EPI_BIAS));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
                                  (int64_t)B * Z, s));
         {
             GemmBatch b{};
-            add(b, make_desc(GK_NT, B, H, Z, acts->z, Z, P[12], Z, acts->d1, H, EPI_BIAS_RELU, P[13]));
+            add(b, fwd(acts->z, Z, 6, H, acts->d1, EPI_BIAS_RELU));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_NT, B, H, H, acts->d1, H, P[14], H, acts->d2, H, EPI_BIAS_RELU, P[15]));
+            add(b, fwd(acts->d1, H, 7, H, acts->d2, EPI_BIAS_RELU));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         int n_recon = 0;
         {  // decoder output + MSE gradient + MSE partial sums in one epilogue (lightning.py:113)
             GemmBatch b{};
-            GemmDesc d = make_desc(GK_NT, B, D, H, acts->d2, H, P[16], H, x_hat, D, EPI_BIAS_RECON, P[17]);
+            GemmDesc d = fwd(acts->d2, H, 8, D, x_hat, EPI_BIAS_RECON);
             d.aux2 = x;
             d.C2 = sc.gy;
             d.go = grad_loss;

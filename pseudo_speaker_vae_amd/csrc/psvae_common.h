@@ -144,6 +144,8 @@ hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const flo
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);
+hipError_t launch_transpose_f32(const float* const* src, float* const* dst, const int* R, const int* C, int n,
+                                hipStream_t s);
 hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1, const float* b1, const float* W2,
                            const float* b2, float* z, int target, float step_size, float noise_weight,
                            int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
