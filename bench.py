@@ -140,6 +140,7 @@ def main():
                     help="train = cfg2 (headline); decode = cfg5: decode-only sampling, --samples rows in total")
     ap.add_argument("--samples", type=int, default=1_000_000, help="decode workload: rows over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="skip the launch-plan autotuning (heuristic configs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,6 +179,9 @@ def main():
     if args.cond:
         eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
 
+    plan = "untuned"
+    if not args.no_tune:
+        plan = eng.tune(x)  # launch-plan autotuning, once per shape, outside the timed region
     mode = args.mode
     if mode == "auto":
         mode = "graph"
@@ -252,7 +256,7 @@ def main():
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
                                    f"batch={B}/GPU, global_batch={B * world}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
-                       "launch": mode, "parallelism": f"dp{world}"},
+                       "launch": mode, "parallelism": f"dp{world}", "launch_plan": plan},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5)},

@@ -88,6 +88,8 @@ typedef struct psvae_acts {
 int psvae_version(void);
 /* tuning hook: force the GEMM config (1..9, see gemm_f32.hip) of every later launch; 0 = automatic */
 int psvae_debug_force_tile(int tile);
+/* tuning hook: weight-gradient GEMMs cut the batch over s workgroups per output tile (1..4); 0 = automatic */
+int psvae_debug_force_wgrad_split(int s);
 const char* psvae_strerror(int code);
 
 /* bytes of scratch the calls below need for a batch of B rows (any call; take the max over calls) */
@@ -137,6 +139,16 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
                          uint64_t* rng_state /* nullable */, const psvae_acts* acts, float* x_hat, float* mu,
                          float* logvar, float beta, const float* grad_loss /* nullable = 1 */,
                          const psvae_grads* grads, float* loss3, void* scratch, uint32_t phases, void* stream);
+
+/* Optional, once per (B, D, Z): time the fused step under candidate launch plans (GEMM config per launch, weight-
+ * gradient split, workgroups per CU, tile order) and keep the fastest for later psvae_train_step_f32 calls in this
+ * process.  Runs the step a few thousand times on `stream` (not while capturing) and overwrites acts / outputs /
+ * grads / loss3.  Every plan computes the same result; only speed differs. */
+int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
+                              const psvae_acts* acts, float* x_hat, float* mu, float* logvar,
+                              const psvae_grads* grads, float* loss3, void* scratch, int iters, void* stream);
+/* text form of the plan in use for (B, D, Z) ("untuned" if none) */
+int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n);
 
 /* bf16 variant of psvae_train_step_f32 (BASELINE config 3: bf16 MFMA operands, fp32 accumulate, fp32 master
  * weights, gradients and loss).  D and Z must be multiples of 32.  x, params, grads, outputs, eps_out[B,Z] and

@@ -12,7 +12,8 @@ from typing import Optional, Sequence
 import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libpsvae_hip.so")
+# PSVAE_LIB: tuning only -- load another build of the same ABI (tools/build_variant.sh)
+LIB_PATH = os.environ.get("PSVAE_LIB") or os.path.join(PKG, "libpsvae_hip.so")
 
 NPARAM = 18
 HIDDEN = 512
@@ -24,8 +25,9 @@ ABI_VERSION = 1
 
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
-    "psvae_version", "psvae_debug_force_tile", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
+    "psvae_version", "psvae_debug_force_tile", "psvae_debug_force_wgrad_split", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
+    "psvae_tune_train_step_f32", "psvae_describe_plan",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
 )
@@ -85,6 +87,11 @@ def lib() -> C.CDLL:
     L.psvae_elbo_f32.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, f32, vp, vp, u32, vp]
     L.psvae_backward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), C.POINTER(Acts),
                                      vp, vp, vp, vp, vp, vp, C.c_int, f32, vp, C.POINTER(Grads), vp, vp, u32, u32, vp]
+    L.psvae_tune_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Acts), vp, vp, vp,
+                                            C.POINTER(Grads), vp, vp, C.c_int, vp]
+    L.psvae_tune_train_step_f32.restype = C.c_int
+    L.psvae_describe_plan.argtypes = [C.POINTER(Dims), C.c_char_p, C.c_size_t]
+    L.psvae_describe_plan.restype = C.c_int
     L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
                                        vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_bf16_scratch_bytes.restype = C.c_size_t
@@ -101,7 +108,7 @@ def lib() -> C.CDLL:
     f64 = C.c_double
     L.psvae_adam_step_f32.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64, f64, vp]
     for fn in ("psvae_philox_normal_f32", "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32",
-               "psvae_train_step_f32", "psvae_debug_force_tile",
+               "psvae_train_step_f32", "psvae_debug_force_tile", "psvae_debug_force_wgrad_split",
                "psvae_decode_f32", "psvae_gemm_f32", "psvae_adam_step_f32"):
         getattr(L, fn).restype = C.c_int
     if L.psvae_version() != ABI_VERSION:
@@ -115,12 +122,15 @@ def check(code: int, what: str = "") -> None:
         raise PsvaeError(f"{what}: {lib().psvae_strerror(code).decode()} (code {code})")
 
 
-def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, None for None."""
+def ptr(t: Optional[torch.Tensor], pitched: bool = False) -> Optional[int]:
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, None for None.  `pitched` also admits a
+    2-D row-pitched view (unit inner stride) for the entry points that take a leading dimension."""
     if t is None:
         return None
     if not t.is_cuda:
         raise PsvaeError("psvae kernels need tensors on the GPU (cuda:N); got a CPU tensor and there is no CPU path")
+    if pitched and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t.data_ptr()
     if not t.is_contiguous():
         raise PsvaeError("psvae kernels need contiguous tensors")
     return t.data_ptr()

@@ -503,6 +503,51 @@ hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int np
 }
 
 // ---------------------------------------------------------------------------------------------
+// cross-workgroup split-K: sum the partial slabs of up to 18 gradient tensors in fixed order
+// ---------------------------------------------------------------------------------------------
+struct SlabReduceArgs {
+    const float* src[18];
+    float* dst[18];
+    long long numel[18];
+    int S[18];
+    int n;
+};
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs a) {
+    const int i = blockIdx.y;
+    const long long n = a.numel[i];
+    const float* __restrict__ src = a.src[i];
+    float* __restrict__ dst = a.dst[i];
+    const int S = a.S[i];
+    const bool v4 = ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    if (v4) {
+        for (long long e = 4 * ((long long)blockIdx.x * 256 + threadIdx.x); e < n; e += 4LL * gridDim.x * 256) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(src + e);
+            for (int s = 1; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(src + (size_t)s * n + e);
+            *reinterpret_cast<f32x4*>(dst + e) = acc;
+        }
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+            float acc = src[e];
+            for (int s = 1; s < S; ++s) acc += src[(size_t)s * n + e];
+            dst[e] = acc;
+        }
+    }
+}
+hipError_t launch_slab_reduce(const float* const* src, float* const* dst, const int64_t* numel, const int* S, int n,
+                              hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    SlabReduceArgs a{};
+    long long mx = 0;
+    for (int i = 0; i < n; ++i) {
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.numel[i] = numel[i]; a.S[i] = S[i];
+        mx = numel[i] > mx ? numel[i] : mx;
+    }
+    a.n = n;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((mx + 3) / 4, 256, 256), n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // grouped fp32 transposes: dst[i] [C,R] = src[i] [R,C]^T (32x32 LDS tiles, whole 128-B rows both ways).
 // The forward wants the weights k-MAJOR ([in,out]): a k-contiguous weight operand is read in 64-B pieces
 // (half of every 128-B line), which halves the per-CU feed rate of the register-direct GEMM.

@@ -98,7 +98,7 @@ template <int T, bool KM>
 __device__ __forceinline__ int slot_index(int blk, int slot) { return KM ? T * slot + blk : 16 * blk + slot; }
 
 template <int TM, int TN, int WM, int WN, int KS, int D, bool AKM, bool BKM>
-__device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, float* __restrict__ smem) {
+__device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     constexpr int NW = WM * WN * KS;  // waves per workgroup: 4 or 8
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int NT = 64 * NW;
@@ -133,10 +133,14 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     for (int m = 0; m < TM; ++m) csum[m] = 0.f;
     const bool do_colsum = AKM && (d.colsum != nullptr) && (tn == 0) && (wn == 0);
 
-    // this wave's chunk range [cbeg, cend) of the ceil(K/16) chunks
-    const int nc = (K + 15) >> 4;
-    const int per = (nc + KS - 1) / KS;
-    const int cbeg = ks * per;
+    // chunk range: the ceil(K/16) chunks are cut over the `ksplit` workgroup slices (cross-workgroup split-K:
+    // slice ksg writes a partial tile), and this workgroup's share over its KS waves
+    const int nc_all = (K + 15) >> 4;
+    const int per_wg = (nc_all + d.ksplit - 1) / d.ksplit;
+    const int wbeg = ksg * per_wg;
+    const int nc = (wbeg + per_wg < nc_all) ? wbeg + per_wg : nc_all;  // end of this workgroup's range
+    const int per = (nc - wbeg + KS - 1) / KS;
+    const int cbeg = wbeg + ks * (per > 0 ? per : 0);
     const int cend = (cbeg + per < nc) ? cbeg + per : nc;
 
     float fa[D][4][TM], fb[D][4][TN];
@@ -159,24 +163,33 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
 
     int c = cbeg;
     if (vec) {
-        // fast region: whole groups of D chunks that are interior in k -- straight-line code, the next
-        // group's loads issued right behind the MFMAs that free their registers, counted vmcnt waits
+        // fast region: whole groups of D chunks that are interior in k.  Software pipeline over a ring of D
+        // fragment slots: at the top of chunk i the loads of chunk i+D-1 are issued, then chunk i (whose
+        // loads left D-1 chunks ago) is multiplied.  The sched_barriers pin that order: left alone, the
+        // scheduler sinks every load of a group below the group's last MFMA and the next iteration stalls
+        // on them at once (measured: ~35 % of wave time in s_waitcnt).
         const int cf_end = cend < (K >> 4) ? cend : (K >> 4);
         const int nfull = cf_end > cbeg ? (cf_end - cbeg) / D : 0;
         if (nfull > 0) {
 #pragma unroll
-            for (int s = 0; s < D; ++s) {
+            for (int s = 0; s < D - 1; ++s) {
                 load_frag<TM, AKM, true>(fa[s], A, lda, am, M, K, cbeg + s, r, q);
                 load_frag<TN, BKM, true>(fb[s], B, ldb, bn, N, K, cbeg + s, r, q);
             }
-            for (int g = 1; g < nfull; ++g) {
+            for (int g = 0; g < nfull - 1; ++g) {
 #pragma unroll
                 for (int s = 0; s < D; ++s) {
+                    const int ls = (s + D - 1) % D;
+                    load_frag<TM, AKM, true>(fa[ls], A, lda, am, M, K, cbeg + g * D + s + D - 1, r, q);
+                    load_frag<TN, BKM, true>(fb[ls], B, ldb, bn, N, K, cbeg + g * D + s + D - 1, r, q);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(s);
-                    load_frag<TM, AKM, true>(fa[s], A, lda, am, M, K, cbeg + g * D + s, r, q);
-                    load_frag<TN, BKM, true>(fb[s], B, ldb, bn, N, K, cbeg + g * D + s, r, q);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            load_frag<TM, AKM, true>(fa[D - 1], A, lda, am, M, K, cbeg + nfull * D - 1, r, q);
+            load_frag<TN, BKM, true>(fb[D - 1], B, ldb, bn, N, K, cbeg + nfull * D - 1, r, q);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < D; ++s) mma(s);
             c = cbeg + nfull * D;
@@ -225,7 +238,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     }
     __syncthreads();
     const int epi = d.epi;
-    float* __restrict__ C = d.C;
+    float* __restrict__ C = d.C + (size_t)ksg * M * d.ldc;  // ksplit > 1: this slice's slab
     const float* __restrict__ aux = d.aux;
     const int ldc = d.ldc;
     const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -330,7 +343,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
         float s = csum_s[tid];
 #pragma unroll
         for (int k2 = 1; k2 < KS; ++k2) s += csum_s[k2 * BM + tid];
-        if (m0 + tid < M) stg<float>(d.colsum + m0 + tid, s);
+        if (m0 + tid < M) stg<float>(d.colsum + (size_t)ksg * M + m0 + tid, s);
     }
 }
 
@@ -339,15 +352,21 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
 template <int ID> struct CfgT;
 #define PSVAE_CFG(ID, TM_, TN_, WM_, WN_, KS_, D_) \
     template <> struct CfgT<ID> { static constexpr int TM = TM_, TN = TN_, WM = WM_, WN = WN_, KS = KS_, D = D_; }
-PSVAE_CFG(1, 2, 2, 1, 1, 4, 4);  // 32x32   tile, k split 4
-PSVAE_CFG(2, 2, 4, 1, 1, 4, 4);  // 32x64   tile, k split 4
-PSVAE_CFG(3, 4, 2, 1, 1, 4, 4);  // 64x32   tile, k split 4
-PSVAE_CFG(4, 2, 2, 1, 2, 2, 4);  // 32x64   tile, k split 2
-PSVAE_CFG(5, 2, 2, 2, 2, 1, 4);  // 64x64   tile, no split
-PSVAE_CFG(6, 4, 4, 1, 1, 4, 2);  // 64x64   tile, k split 4
-PSVAE_CFG(7, 4, 4, 2, 2, 1, 2);  // 128x128 tile, no split (large batches)
-PSVAE_CFG(8, 1, 2, 1, 1, 4, 4);  // 16x32   tile, k split 4 (small outputs, long k)
-PSVAE_CFG(9, 4, 4, 1, 2, 2, 2);  // 64x128  tile, k split 2
+#ifndef PSVAE_D_BIG
+#define PSVAE_D_BIG 2  // ring slots of the 4x4-block wave tiles (32 VGPRs per slot)
+#endif
+#ifndef PSVAE_D_SMALL
+#define PSVAE_D_SMALL 4  // ring slots of the smaller wave tiles
+#endif
+PSVAE_CFG(1, 2, 2, 1, 1, 4, PSVAE_D_SMALL);  // 32x32   tile, k split 4
+PSVAE_CFG(2, 2, 4, 1, 1, 4, PSVAE_D_SMALL);  // 32x64   tile, k split 4
+PSVAE_CFG(3, 4, 2, 1, 1, 4, PSVAE_D_SMALL);  // 64x32   tile, k split 4
+PSVAE_CFG(4, 2, 2, 1, 2, 2, PSVAE_D_SMALL);  // 32x64   tile, k split 2
+PSVAE_CFG(5, 2, 2, 2, 2, 1, PSVAE_D_SMALL);  // 64x64   tile, no split
+PSVAE_CFG(6, 4, 4, 1, 1, 4, PSVAE_D_BIG);    // 64x64   tile, k split 4
+PSVAE_CFG(7, 4, 4, 2, 2, 1, PSVAE_D_BIG);    // 128x128 tile, no split (large batches)
+PSVAE_CFG(8, 1, 2, 1, 1, 4, PSVAE_D_SMALL);  // 16x32   tile, k split 4 (small outputs, long k)
+PSVAE_CFG(9, 4, 4, 1, 2, 2, PSVAE_D_BIG);    // 64x128  tile, k split 2
 // (8-wave workgroups with k split 8 were measured too -- tools: profiles/r01 sweep -- and were never
 // faster than these; the tile code supports them: NW = WM*WN*KS may be 4 or 8)
 constexpr int NCFG = 9;
@@ -364,14 +383,14 @@ static const Cfg kCfgs[NCFG] = {
 };
 
 template <int ID>
-__device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, float* __restrict__ smem) {
+__device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     typedef CfgT<ID> C;
     if (d.kind == GK_NT)
-        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, false>(d, tm, tn, smem);
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, false>(d, tm, tn, ksg, smem);
     else if (d.kind == GK_NN)
-        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, true>(d, tm, tn, smem);
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, true>(d, tm, tn, ksg, smem);
     else
-        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, true, true>(d, tm, tn, smem);
+        gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, true, true>(d, tm, tn, ksg, smem);
 }
 
 // One launch = a group of problems with up to TWO configs: the long-k wgrad problems (TN) run C0 (small
@@ -393,15 +412,18 @@ __global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) vo
     const GemmDesc& d = batch.d[di];
     int lt = tile - d.tile_begin;
     if (batch.xcd_remap) {  // within one problem (every XCD keeps its share of heavy and light problems)
-        const int T = d.tiles_m * d.tiles_n, q8 = T >> 3, r8 = T & 7;
+        const int T = d.tiles_m * d.tiles_n * d.ksplit, q8 = T >> 3, r8 = T & 7;
         const int xcd = lt & 7, idx = lt >> 3;
         lt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
+    const int tiles_mn = d.tiles_m * d.tiles_n;
+    const int ksg = lt / tiles_mn;  // cross-workgroup k slice (0 when ksplit == 1)
+    lt -= ksg * tiles_mn;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
     if (C0 == C1 || d.cfg == C0)
-        run_cfg<C0>(d, tm, tn, smem);
+        run_cfg<C0>(d, tm, tn, ksg, smem);
     else
-        run_cfg<C1>(d, tm, tn, smem);
+        run_cfg<C1>(d, tm, tn, ksg, smem);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -419,8 +441,9 @@ int num_gemm_configs() { return NCFG; }
 // max(one workgroup, per-CU share quantised to whole rounds).
 static double estimate(const GemmDesc& d, const Cfg& c, double slots) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
-    const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    const int chunks = (d.K + 15) / 16;
+    const int S = d.ksplit > 1 ? d.ksplit : 1;
+    const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * S;
+    const int chunks = ((d.K + 15) / 16 + S - 1) / S;
     const int per = (chunks + c.KS - 1) / c.KS;
     const int full = per / c.D * c.D, rem = per - full;
     double per_chunk = 4.0 * c.TM * c.TN * 32.0 / c.eff;
@@ -438,7 +461,7 @@ int pick_tile(const GemmBatch& b) {  // config of the first problem (test hook s
     return c.d[0].cfg;
 }
 
-static const int kTnCands[] = {1, 8};              // wgrad: small tiles, k split 4
+static const int kTnCands[] = {1, 8};              // wgrad: small tiles, k split 4 (a tuned plan may also pick 2 or 6)
 static const int kOtherCands[] = {1, 2, 4, 6, 8};  // forward / dgrad
 
 // cfg == 0: choose one config for the TN problems and one for the others; else force `cfg` everywhere
@@ -452,10 +475,7 @@ void finalize_batch(GemmBatch& b, int cfg) {
     }
     int pick_tn = cfg, pick_other = cfg;
     static const int force_tn = env_int("PSVAE_CFG_TN", 0), force_other = env_int("PSVAE_CFG_OTHER", 0);  // tuning
-    if (cfg == 0 && force_tn && force_other) {
-        pick_tn = force_tn;
-        pick_other = force_other;
-    } else if (cfg == 0) {
+    if (cfg == 0) {
         // each class gets its FLOP share of the 256 CUs (at least 32: small problems ride in the
         // others' tails); within a class the slowest problem decides
         for (int cls = 0; cls < 2; ++cls) {
@@ -476,6 +496,10 @@ void finalize_batch(GemmBatch& b, int cfg) {
             }
             (cls ? pick_other : pick_tn) = pick;
         }
+        if (force_tn > 0 && force_tn <= NCFG) pick_tn = force_tn;
+        if (force_other > 0 && force_other <= NCFG) pick_other = force_other;
+        if (b.hint_tn > 0 && b.hint_tn <= NCFG) pick_tn = b.hint_tn;  // a tuned plan wins
+        if (b.hint_other > 0 && b.hint_other <= NCFG) pick_other = b.hint_other;
     }
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
@@ -486,12 +510,13 @@ void finalize_batch(GemmBatch& b, int cfg) {
         d.tiles_m = (d.M + BM - 1) / BM;
         d.tiles_n = (d.N + BN - 1) / BN;
         d.tile_begin = t;
-        t += d.tiles_m * d.tiles_n;
+        if (d.ksplit < 1) d.ksplit = 1;
+        t += d.tiles_m * d.tiles_n * d.ksplit;
     }
     b.total_tiles = t;
     b.dbg = 0;
     static const int remap = env_int("PSVAE_XCD_REMAP", 0);  // measured: no gain at these sizes (L2 fills are not the limiter)
-    b.xcd_remap = remap;
+    b.xcd_remap = b.hint_remap ? (b.hint_remap == 1) : remap;
 }
 
 static size_t lds_bytes(const Cfg& c) {
@@ -502,9 +527,9 @@ static size_t lds_bytes(const Cfg& c) {
 template <int C0, int C1>
 static hipError_t launch_pair(const GemmBatch& b, size_t lds, hipStream_t stream) {
     static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    if (!attr_done && lds > 48 * 1024) {  // (the limit is set once, to the most any config or PSVAE_LDS_MIN asks)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -527,11 +552,19 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     }
     if (c0 == 0) c0 = c1;
     if (c1 == 0) c1 = c0;
+    // Two co-resident workgroups of these kernels share one L1 and run slower than one after the other
+    // (measured: 512 workgroups of config 6 take 37 us co-resident, 26 us capped), so a launch may ask for more
+    // than half the CU's LDS to keep one workgroup per CU.
+    static const int lds_min = env_int("PSVAE_LDS_MIN", 0);  // tuning
+    if ((size_t)lds_min > lds) lds = lds_min;
+    if (b.hint_cap == 1 && lds < 82 * 1024) lds = 82 * 1024;
 #define PSVAE_PAIR(A, B) if (c0 == A && c1 == B) return launch_pair<A, B>(b, lds, stream)
     PSVAE_PAIR(1, 1); PSVAE_PAIR(2, 2); PSVAE_PAIR(3, 3); PSVAE_PAIR(4, 4); PSVAE_PAIR(5, 5);
     PSVAE_PAIR(6, 6); PSVAE_PAIR(7, 7); PSVAE_PAIR(8, 8); PSVAE_PAIR(9, 9);
     PSVAE_PAIR(1, 2); PSVAE_PAIR(1, 4); PSVAE_PAIR(1, 6); PSVAE_PAIR(1, 8);
     PSVAE_PAIR(8, 1); PSVAE_PAIR(8, 2); PSVAE_PAIR(8, 4); PSVAE_PAIR(8, 6);
+    PSVAE_PAIR(6, 1); PSVAE_PAIR(6, 2); PSVAE_PAIR(6, 4); PSVAE_PAIR(6, 8);
+    PSVAE_PAIR(2, 1); PSVAE_PAIR(2, 4); PSVAE_PAIR(2, 6); PSVAE_PAIR(2, 8);
 #undef PSVAE_PAIR
     return hipErrorInvalidValue;
 }

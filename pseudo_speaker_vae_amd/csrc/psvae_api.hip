@@ -3,6 +3,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "psvae_common.h"
 
 using namespace psvae;
@@ -19,10 +23,27 @@ int check_dims(const psvae_dims* d) {
     return 0;
 }
 
+// The weight-gradient GEMMs dW = dY^T X reduce over the batch.  With one workgroup per output tile the tiles
+// must be small (32x32) to fill 256 CUs, and small tiles re-read their operand panels from L2 so often that
+// the launch is bound by L2->L1 traffic, not MFMA.  Cutting the batch over S workgroups per tile allows 64x64
+// tiles at the same workgroup count (half the traffic); the S partial tiles go to slabs that one
+// slab_reduce launch per phase sums in fixed order (bitwise reproducible, no atomics).
+constexpr int WGRAD_SMAX = 4;
+int g_wgrad_forced = -1;  // -1: read PSVAE_WGRAD_S once; psvae_debug_force_wgrad_split overrides (0 = automatic)
+inline int wgrad_ksplit(int64_t B) {
+    if (g_wgrad_forced < 0) g_wgrad_forced = getenv("PSVAE_WGRAD_S") ? atoi(getenv("PSVAE_WGRAD_S")) : 0;
+    const int forced = g_wgrad_forced;
+    if (forced >= 1 && forced <= WGRAD_SMAX) return forced;
+    (void)B;
+    return 1;  // untuned default: no split (the tuner enables it per launch where the whole step gets faster)
+}
+
 // scratch carve (floats), identical for every call so phases can share it
 struct Scratch {
     float *y, *gy, *dd2, *dd1, *gz, *gmu, *glv, *dh2m, *dh2s, *dh1m, *dh1s, *partials, *kl_partials, *recon_partials;
     float* wt[9];  // k-major ([in,out]) copies of the 9 weight matrices for the fused step's forward
+    float* slab_w[9];  // cross-workgroup split-K partials of the 9 weight gradients, [WGRAD_SMAX][out*in]
+    float* slab_b[9];  // ... and of the 9 bias gradients, [WGRAD_SMAX][out]
     int n_recon_max;
     size_t bytes;
 };
@@ -53,10 +74,39 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
     {
         const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
         for (int k = 0; k < 9; ++k) s.wt[k] = take((size_t)(o[k] * in[k]));
+        for (int k = 0; k < 9; ++k) s.slab_w[k] = take((size_t)(WGRAD_SMAX * o[k] * in[k]));
+        for (int k = 0; k < 9; ++k) s.slab_b[k] = take((size_t)(WGRAD_SMAX * o[k]));
     }
     s.bytes = off;
     return s;
 }
+
+// weight gradient k (0..8): dW_k[M=out, N=in] = dY^T X over the batch, bias gradient = column sums of dY^T;
+// with S > 1 the partials go to the slabs and reduce() finishes them
+struct WgradPlan {
+    int S, B;
+    const Scratch& sc;
+    float* const* G;
+    const float* src[18];
+    float* dst[18];
+    int64_t num[18];
+    int rS[18];
+    int n;
+    WgradPlan(int B_, const Scratch& sc_, float* const* G_) : S(wgrad_ksplit(B_)), B(B_), sc(sc_), G(G_), n(0) {}
+    GemmDesc desc(int k, int M, int N, const float* dY, const float* X) {
+        if (S == 1) return make_desc(GK_TN, M, N, B, dY, M, X, N, G[2 * k], N, EPI_NONE, nullptr, G[2 * k + 1]);
+        GemmDesc d = make_desc(GK_TN, M, N, B, dY, M, X, N, sc.slab_w[k], N, EPI_NONE, nullptr, sc.slab_b[k]);
+        d.ksplit = S;
+        src[n] = sc.slab_w[k]; dst[n] = G[2 * k]; num[n] = (int64_t)M * N; rS[n++] = S;
+        src[n] = sc.slab_b[k]; dst[n] = G[2 * k + 1]; num[n] = M; rS[n++] = S;
+        return d;
+    }
+    hipError_t reduce(hipStream_t s) {
+        const hipError_t e = launch_slab_reduce(src, dst, num, rS, n, s);
+        n = 0;
+        return e;
+    }
+};
 
 #define RET_IF(e)                            \
     do {                                     \
@@ -82,6 +132,12 @@ int psvae_version(void) { return PSVAE_ABI_VERSION; }
 int psvae_debug_force_tile(int tile) {
     if (tile < 0 || tile > num_gemm_configs()) return PSVAE_ERR_ARG;
     debug_force_tile(tile);
+    return 0;
+}
+
+int psvae_debug_force_wgrad_split(int s) {
+    if (s < 0 || s > WGRAD_SMAX) return PSVAE_ERR_ARG;
+    g_wgrad_forced = s;
     return 0;
 }
 
@@ -216,6 +272,7 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
     const float* const* P = params->p;
     float* const* G = grads->g;
     Scratch sc = carve(scratch, B, D, Z);
+    WgradPlan wg(B, sc, G);
 
     if (phases & PSVAE_PHASE_DECODER) {
         const float* gy;
@@ -228,19 +285,19 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
         }
         {  // decoder.4: dW = gy^T d2, db = colsum(gy); dd2 = (gy W) * [d2 > 0]
             GemmBatch b{};
-            add(b, make_desc(GK_TN, D, H, B, gy, D, acts->d2, H, G[16], H, EPI_NONE, nullptr, G[17]));
+            add(b, wg.desc(8, D, H, gy, acts->d2));
             add(b, make_desc(GK_NN, B, H, D, gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // decoder.2
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, H, B, sc.dd2, H, acts->d1, H, G[14], H, EPI_NONE, nullptr, G[15]));
+            add(b, wg.desc(7, H, H, sc.dd2, acts->d1));
             add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // decoder.0: dW = dd1^T z ; g_z = dd1 W
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, Z, B, sc.dd1, H, acts->z, Z, G[12], Z, EPI_NONE, nullptr, G[13]));
+            add(b, wg.desc(6, H, Z, sc.dd1, acts->z));
             add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
@@ -251,28 +308,29 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             float* gt[1] = {cond->gtab[2]};
             RET_IF(launch_cond_colsum(dy, gt, 1, cond->gender, cond->age, B, H, s));
         }
+        if (!(phases & PSVAE_PHASE_ENCODER)) RET_IF(wg.reduce(s));  // decoder-only call: finish its gradients
     }
     if (phases & PSVAE_PHASE_ENCODER) {
         {  // encoder_*.4
             GemmBatch b{};
-            add(b, make_desc(GK_TN, Z, H, B, sc.gmu, Z, acts->h2m, H, G[4], H, EPI_NONE, nullptr, G[5]));
-            add(b, make_desc(GK_TN, Z, H, B, sc.glv, Z, acts->h2s, H, G[10], H, EPI_NONE, nullptr, G[11]));
+            add(b, wg.desc(2, Z, H, sc.gmu, acts->h2m));
+            add(b, wg.desc(5, Z, H, sc.glv, acts->h2s));
             add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
             add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // encoder_*.2
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, H, B, sc.dh2m, H, acts->h1m, H, G[2], H, EPI_NONE, nullptr, G[3]));
-            add(b, make_desc(GK_TN, H, H, B, sc.dh2s, H, acts->h1s, H, G[8], H, EPI_NONE, nullptr, G[9]));
+            add(b, wg.desc(1, H, H, sc.dh2m, acts->h1m));
+            add(b, wg.desc(4, H, H, sc.dh2s, acts->h1s));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // encoder_*.0 (x needs no gradient in the reference: no dgrad)
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, D, B, sc.dh1m, H, x, D, G[0], D, EPI_NONE, nullptr, G[1]));
-            add(b, make_desc(GK_TN, H, D, B, sc.dh1s, H, x, D, G[6], D, EPI_NONE, nullptr, G[7]));
+            add(b, wg.desc(0, H, D, sc.dh1m, x));
+            add(b, wg.desc(3, H, D, sc.dh1s, x));
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         if (has_cond) {
@@ -280,6 +338,7 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             float* gt[2] = {cond->gtab[0], cond->gtab[1]};
             RET_IF(launch_cond_colsum(dy, gt, 2, cond->gender, cond->age, B, H, s));
         }
+        RET_IF(wg.reduce(s));
         if (g_x) {  // optional: d/dx = dh1m W1m + dh1s W1s (two dependent launches: the second accumulates)
             GemmBatch b1{};
             add(b1, make_desc(GK_NN, B, D, H, sc.dh1m, H, P[0], D, g_x, D, EPI_NONE, nullptr));
@@ -292,10 +351,28 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
     return 0;
 }
 
+// ---- tuned launch plans of the fused step -----------------------------------------------------------
+// key (B, D, Z) -> plan; filled by psvae_tune_train_step_f32, read at every train-step call (also while a HIP
+// graph is being captured: the captured launches carry the tuned configs).
+static std::mutex g_plan_mu;
+static std::map<std::tuple<int64_t, int64_t, int64_t>, StepPlan> g_plans;
+static const StepPlan* g_trial = nullptr;  // the tuner's candidate (single-threaded use under g_tune_mu)
+static std::mutex g_tune_mu;
+
+static bool find_plan(int64_t B, int64_t D, int64_t Z, StepPlan* out) {
+    if (g_trial) { *out = *g_trial; return true; }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(std::make_tuple(B, D, Z));
+    if (it == g_plans.end()) return false;
+    *out = it->second;
+    return true;
+}
+
 // forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs:
 //   reparam also emits KL partial sums; the last decoder GEMM's epilogue also writes the MSE gradient and
 //   MSE partial sums; the reparam-backward kernel also finishes the loss and advances the Philox state.
-// 14 launches instead of 19.  Only for the default loss (MSE/10, no decoder normalisation).
+// 15 launches (+1 when a weight gradient is split over workgroups) instead of 19.  Only for the default loss
+// (MSE/10, no decoder normalisation).
 int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const float* eps_in,
                          uint64_t seed, uint64_t offset, uint64_t* rng_state, const psvae_acts* acts, float* x_hat,
                          float* mu, float* logvar, float beta, const float* grad_loss, const psvae_grads* grads,
@@ -313,6 +390,8 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     float* const* G = grads->g;
     Scratch sc = carve(scratch, B, D, Z);
     const int n_kl = reparam_blocks((int64_t)B * Z);
+    StepPlan plan{};
+    find_plan(B, D, Z, &plan);  // all-zero (heuristics) when this shape was never tuned
 
     static const bool kmajor_w = getenv("PSVAE_FWD_NT") == nullptr;  // default: forward reads k-major weight copies
     // forward Linear l:  Y = X W^T.  With the k-major copy WT[in,out] it is the NN product X * WT, whose weight
@@ -320,6 +399,18 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     auto fwd = [&](const float* X, int K, int wk, int N, float* Y, int epi) {
         return kmajor_w ? make_desc(GK_NN, B, N, K, X, K, sc.wt[wk], N, Y, N, epi, P[2 * wk + 1])
                         : make_desc(GK_NT, B, N, K, X, K, P[2 * wk], K, Y, N, epi, P[2 * wk + 1]);
+    };
+    auto launch = [&](GemmBatch& b, int site) {
+        const SitePlan& sp = plan.site[site];
+        b.hint_tn = sp.cfg_tn; b.hint_other = sp.cfg_other; b.hint_cap = sp.cap; b.hint_remap = sp.remap;
+        return launch_gemm_batch(b, 0, s);
+    };
+    WgradPlan wg(B, sc, G);
+    const int S_default = wg.S;
+    auto wgrad = [&](int site, int k, int M, int N, const float* dY, const float* X) {
+        const int S = plan.site[site].ksplit;
+        wg.S = (S >= 1 && S <= WGRAD_SMAX) ? S : S_default;
+        return wg.desc(k, M, N, dY, X);
     };
     if (phases & PSVAE_PHASE_DECODER) {
         if (kmajor_w) {
@@ -332,31 +423,31 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             GemmBatch b{};
             add(b, fwd(x, D, 0, H, acts->h1m, EPI_BIAS_RELU));
             add(b, fwd(x, D, 3, H, acts->h1s, EPI_BIAS_RELU));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 0));
         }
         {
             GemmBatch b{};
             add(b, fwd(acts->h1m, H, 1, H, acts->h2m, EPI_BIAS_RELU));
             add(b, fwd(acts->h1s, H, 4, H, acts->h2s, EPI_BIAS_RELU));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 1));
         }
         {
             GemmBatch b{};
             add(b, fwd(acts->h2m, H, 2, Z, mu, EPI_BIAS));
             add(b, fwd(acts->h2s, H, 5, Z, logvar, EPI_BIAS));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 2));
         }
         RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
                                  (int64_t)B * Z, s));
         {
             GemmBatch b{};
             add(b, fwd(acts->z, Z, 6, H, acts->d1, EPI_BIAS_RELU));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 3));
         }
         {
             GemmBatch b{};
             add(b, fwd(acts->d1, H, 7, H, acts->d2, EPI_BIAS_RELU));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 4));
         }
         int n_recon = 0;
         {  // decoder output + MSE gradient + MSE partial sums in one epilogue (lightning.py:113)
@@ -368,56 +459,146 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             d.scale = 2.0f / (10.0f * (float)B * (float)D);
             d.partials = sc.recon_partials;
             add(b, d);
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 5));
             n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
             if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, D, H, B, sc.gy, D, acts->d2, H, G[16], H, EPI_NONE, nullptr, G[17]));
+            add(b, wgrad(6, 8, D, H, sc.gy, acts->d2));
             add(b, make_desc(GK_NN, B, H, D, sc.gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 6));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, H, B, sc.dd2, H, acts->d1, H, G[14], H, EPI_NONE, nullptr, G[15]));
+            add(b, wgrad(7, 7, H, H, sc.dd2, acts->d1));
             add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 7));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, Z, B, sc.dd1, H, acts->z, Z, G[12], Z, EPI_NONE, nullptr, G[13]));
+            add(b, wgrad(8, 6, H, Z, sc.dd1, acts->z));
             add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 8));
         }
         RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, acts->eps, beta, grad_loss, sc.gmu, sc.glv, B, Z, D,
                                         sc.kl_partials, n_kl, sc.recon_partials, n_recon, loss3,
                                         eps_in ? nullptr : rng_state, s));
+        if (!(phases & PSVAE_PHASE_ENCODER)) {  // a decoder-only call must leave the decoder gradients complete
+            RET_IF(wg.reduce(s));
+        }
     }
     if (phases & PSVAE_PHASE_ENCODER) {
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, Z, H, B, sc.gmu, Z, acts->h2m, H, G[4], H, EPI_NONE, nullptr, G[5]));
-            add(b, make_desc(GK_TN, Z, H, B, sc.glv, Z, acts->h2s, H, G[10], H, EPI_NONE, nullptr, G[11]));
+            add(b, wgrad(9, 2, Z, H, sc.gmu, acts->h2m));
+            add(b, wgrad(9, 5, Z, H, sc.glv, acts->h2s));
             add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
             add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 9));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, H, B, sc.dh2m, H, acts->h1m, H, G[2], H, EPI_NONE, nullptr, G[3]));
-            add(b, make_desc(GK_TN, H, H, B, sc.dh2s, H, acts->h1s, H, G[8], H, EPI_NONE, nullptr, G[9]));
+            add(b, wgrad(10, 1, H, H, sc.dh2m, acts->h1m));
+            add(b, wgrad(10, 4, H, H, sc.dh2s, acts->h1s));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            RET_IF(launch(b, 10));
         }
         {
             GemmBatch b{};
-            add(b, make_desc(GK_TN, H, D, B, sc.dh1m, H, x, D, G[0], D, EPI_NONE, nullptr, G[1]));
-            add(b, make_desc(GK_TN, H, D, B, sc.dh1s, H, x, D, G[6], D, EPI_NONE, nullptr, G[7]));
-            RET_IF(launch_gemm_batch(b, 0, s));
+            add(b, wgrad(11, 0, H, D, sc.dh1m, x));
+            add(b, wgrad(11, 3, H, D, sc.dh1s, x));
+            RET_IF(launch(b, 11));
+        }
+        RET_IF(wg.reduce(s));
+    }
+    return 0;
+}
+
+// Time the whole fused step for each candidate launch plan of each GEMM launch in turn (coordinate descent: the
+// launches interact through the caches, so the objective is the step, not the launch) and keep the fastest plan
+// for this (B, D, Z).  Every candidate computes the same result; only speed differs.
+int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
+                              const psvae_acts* acts, float* x_hat, float* mu, float* logvar,
+                              const psvae_grads* grads, float* loss3, void* scratch, int iters, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (iters < 1 || iters > 1000) return PSVAE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return PSVAE_ERR_STATE;
+    std::lock_guard<std::mutex> tune_lock(g_tune_mu);
+    hipEvent_t e0, e1;
+    RET_IF(hipEventCreate(&e0));
+    RET_IF(hipEventCreate(&e1));
+    int rc = 0;
+    auto measure = [&](const StepPlan& p, float* ms) -> int {
+        g_trial = &p;
+        int r = 0;
+        for (int i = 0; i < 2 + iters && r == 0; ++i) {
+            if (i == 2) hipEventRecord(e0, s);
+            r = psvae_train_step_f32(dims, x, params, nullptr, 1234, (uint64_t)i * 4096, nullptr, acts, x_hat, mu, logvar,
+                                     1.0f, nullptr, grads, loss3, scratch, PSVAE_PHASE_ALL, stream);
+        }
+        g_trial = nullptr;
+        if (r) return r;
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) return (int)hipGetLastError();
+        hipEventElapsedTime(ms, e0, e1);
+        *ms /= (float)iters;
+        return 0;
+    };
+    StepPlan best{};
+    float t_best = 0.f;
+    rc = measure(best, &t_best);
+    static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8};
+    for (int pass = 0; pass < 2 && rc == 0; ++pass) {
+        for (int site = 0; site < NSITE && rc == 0; ++site) {
+            const bool has_tn = site >= 6, has_other = site != 11;
+            for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
+                for (int o = 0; o < (has_other ? 5 : 1) && rc == 0; ++o)
+                    for (int ks = 1; ks <= (has_tn ? WGRAD_SMAX : 1) && rc == 0; ks *= 2)
+                        for (int capv = 1; capv <= 2 && rc == 0; ++capv)
+                            for (int rm = 1; rm <= 2 && rc == 0; ++rm) {
+                                StepPlan p = best;
+                                SitePlan& sp = p.site[site];
+                                sp.cfg_tn = has_tn ? tn_c[a] : 0;
+                                sp.cfg_other = has_other ? ot_c[o] : sp.cfg_tn;
+                                sp.ksplit = has_tn ? (signed char)ks : 0;
+                                sp.cap = (signed char)capv;
+                                sp.remap = (signed char)rm;
+                                if (memcmp(&sp, &best.site[site], sizeof(SitePlan)) == 0) continue;
+                                float t = 0.f;
+                                rc = measure(p, &t);
+                                if (rc == 0 && t < t_best * 0.997f) {  // keep only clear wins (timer noise ~0.2 %)
+                                    t_best = t;
+                                    best = p;
+                                }
+                            }
         }
     }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans[std::make_tuple(dims->B, dims->D, dims->Z)] = best;
+    return 0;
+}
+
+// text form of the plan in use for (B, D, Z): "site:tn/other/ksplit/cap/remap ..." ("untuned" if none)
+int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n) {
+    if (int e = check_dims(dims)) return e;
+    if (!buf || n == 0) return PSVAE_ERR_NULL;
+    StepPlan p{};
+    if (!find_plan(dims->B, dims->D, dims->Z, &p)) {
+        snprintf(buf, n, "untuned");
+        return 0;
+    }
+    static const char* names[NSITE] = {"F1", "F2", "F3", "F5", "F6", "F7", "B1", "B2", "B3", "B4", "B5", "B6"};
+    size_t off = 0;
+    for (int i = 0; i < NSITE && off < n; ++i)
+        off += snprintf(buf + off, n - off, "%s%s:%d/%d/%d/%d/%d", i ? " " : "", names[i], p.site[i].cfg_tn,
+                        p.site[i].cfg_other, p.site[i].ksplit, p.site[i].cap, p.site[i].remap);
     return 0;
 }
 

@@ -43,6 +43,8 @@ struct GemmDesc {
     int lda, ldb, ldc;
     int kind, epi;
     int cfg;  // GEMM config id of this problem (set by finalize_batch)
+    int ksplit;  // > 1: the k range is cut over `ksplit` WORKGROUPS; workgroup slice s writes its partial tile to
+                 // C + s*M*ldc and its partial column sums to colsum + s*M (summed later by launch_slab_reduce)
     int tiles_m, tiles_n;
     int tile_begin;  // first linear tile of this problem inside the launch
 };
@@ -54,7 +56,22 @@ struct GemmBatch {
     int total_tiles;
     int dbg;  // reserved (0)
     int xcd_remap;  // 1: XCD-aware tile order
+    // host-side launch hints of a tuned plan (0 = cost model / default); the kernel ignores them
+    int hint_tn, hint_other;  // config of the TN problems / of the others
+    int hint_cap;             // 1: at most one workgroup per CU (through the LDS request), 2: no cap, 0: default
+    int hint_remap;           // 1: XCD-aware tile order, 2: plain order, 0: default
 };
+
+// A tuned launch plan of the fused train step: one entry per GEMM launch ("site"), chosen by timing the whole
+// step (psvae_tune_train_step_f32).  All-zero = heuristics.
+struct SitePlan {
+    signed char cfg_tn, cfg_other;  // 0 = cost model
+    signed char ksplit;             // weight-gradient cross-workgroup split (0 = default rule)
+    signed char cap;                // see GemmBatch::hint_cap
+    signed char remap;              // see GemmBatch::hint_remap
+};
+constexpr int NSITE = 12;  // F1 F2 F3 F5 F6 F7 B1 B2 B3 B4 B5 B6
+struct StepPlan { SitePlan site[NSITE]; };
 
 // cfg = 1..num_gemm_configs() selects a (wave tile, wave layout, k-split, prefetch depth) config
 // (table in gemm_f32.hip); cfg == 0 picks one from the problem sizes with a cost model (pick_tile).
@@ -70,6 +87,7 @@ inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda
     d.A = A; d.B = B; d.C = C; d.aux = aux; d.colsum = colsum;
     d.ctab = nullptr; d.gender = nullptr; d.age = nullptr;
     d.aux2 = nullptr; d.C2 = nullptr; d.go = nullptr; d.partials = nullptr; d.scale = 1.f;
+    d.ksplit = 1;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.kind = kind; d.epi = epi;
     return d;
 }
@@ -144,6 +162,9 @@ hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const flo
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);
+// dst[i][e] = sum_{s < S[i]} src[i][s*numel[i] + e]   (fixed order: bitwise reproducible), up to 18 tensors
+hipError_t launch_slab_reduce(const float* const* src, float* const* dst, const int64_t* numel, const int* S, int n,
+                              hipStream_t s);
 hipError_t launch_transpose_f32(const float* const* src, float* const* dst, const int* R, const int* C, int n,
                                 hipStream_t s);
 hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1, const float* b1, const float* W2,

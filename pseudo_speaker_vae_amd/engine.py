@@ -165,6 +165,14 @@ class TrainEngine:
         self.averager.reduce_bucket(0)                 # encoder grads + the 3 loss scalars
         self.averager.wait()
 
+    def tune(self, x: torch.Tensor, iters: int = 10) -> str:
+        """Autotune the fused step's launch plan for this batch shape (fp32, default loss, unconditional only;
+        a no-op otherwise).  Takes a few seconds once; later steps -- eager or captured -- use the plan.  Gradients,
+        outputs and the loss buffer are overwritten.  Returns the plan's text form."""
+        if self.dtype != "f32" or self.flags != 0 or self.conditional:
+            return "untuned"
+        return ops.tune_train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters)
+
     def set_labels(self, gender: torch.Tensor, age: torch.Tensor):
         """conditional engines: integer labels in {-1,0,1,2} for the current batch (labels.py maps)"""
         assert self.conditional

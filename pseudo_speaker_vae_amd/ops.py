@@ -40,7 +40,9 @@ def philox_normal(n: int, seed: int, offset: int, device) -> torch.Tensor:
 def gemm(kind: int, A: torch.Tensor, B: torch.Tensor, epi: int = EPI_NONE, aux: Optional[torch.Tensor] = None,
          want_colsum: bool = False, tile: int = 0, out: Optional[torch.Tensor] = None):
     """Test/bench hook: one grouped-kernel GEMM.  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
-    A, B = _f32(A, "A"), _f32(B, "B")
+    # row-pitched views (stride(1) == 1) go through as they are: the C-ABI takes lda / ldb / ldc
+    A, B = (t if (t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1) else _f32(t, n)
+            for t, n in ((A, "A"), (B, "B")))
     if kind == GEMM_NT:
         (M, K), (N, K2) = A.shape, B.shape
     elif kind == GEMM_NN:
@@ -50,8 +52,8 @@ def gemm(kind: int, A: torch.Tensor, B: torch.Tensor, epi: int = EPI_NONE, aux: 
     assert K == K2, "contraction mismatch"
     Cm = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
     cs = torch.empty(M, dtype=torch.float32, device=A.device) if want_colsum else None
-    _ffi.check(_ffi.lib().psvae_gemm_f32(kind, M, N, K, _ffi.ptr(A), A.stride(0), _ffi.ptr(B), B.stride(0),
-                                         _ffi.ptr(Cm), Cm.stride(0), _ffi.ptr(aux), _ffi.ptr(cs), epi, tile,
+    _ffi.check(_ffi.lib().psvae_gemm_f32(kind, M, N, K, _ffi.ptr(A, True), A.stride(0), _ffi.ptr(B, True), B.stride(0),
+                                         _ffi.ptr(Cm, True), Cm.stride(0), _ffi.ptr(aux), _ffi.ptr(cs), epi, tile,
                                          _ffi.stream_ptr()), "gemm")
     return (Cm, cs) if want_colsum else Cm
 
@@ -128,6 +130,26 @@ def train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence
         C.byref(ws.dims), _ffi.ptr(x), C.byref(P), _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state),
         C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv), beta, _ffi.ptr(grad_loss), C.byref(G),
         _ffi.ptr(loss3), _ffi.ptr(ws.scratch), phases, _ffi.stream_ptr()), "train_step")
+
+
+def tune_train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], outs, loss3,
+                    iters: int = 10) -> str:
+    """Autotune the fused step's launch plan for this (B, D, Z) (psvae_tune_train_step_f32): times the whole step
+    under each candidate plan on the current stream -- a second or two -- and keeps the fastest for every later
+    train_step call of this process.  Overwrites ws.acts / outs / grads / loss3.  Returns the plan's text form."""
+    P = _ffi.make_params(params)
+    G = _ffi.make_grads(grads)
+    xh, mu, lv = outs
+    _ffi.check(_ffi.lib().psvae_tune_train_step_f32(
+        C.byref(ws.dims), _ffi.ptr(x), C.byref(P), C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv),
+        C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), iters, _ffi.stream_ptr()), "tune_train_step")
+    return describe_plan(ws)
+
+
+def describe_plan(ws: Workspace) -> str:
+    buf = C.create_string_buffer(1024)
+    _ffi.check(_ffi.lib().psvae_describe_plan(C.byref(ws.dims), buf, 1024), "describe_plan")
+    return buf.value.decode()
 
 
 class Bf16Workspace:

@@ -240,3 +240,62 @@ def test_fused_train_step_matches_unfused_path_and_oracle(ops, D, Z, B):
         assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
     for k, g in zip(O.PARAM_KEYS, grads):
         assert_close(g.cpu(), ograds[k], REL_TOL, "fused vs oracle grad " + k)
+
+
+@pytest.mark.parametrize("D,Z,B", [(256, 64, 1000), (96, 24, 37), (200, 48, 130)])
+def test_wgrad_cross_workgroup_split_matches_oracle(ops, D, Z, B):
+    """Weight gradients with the batch cut over S workgroups per tile (partials in slabs, summed in fixed
+    order) agree with the unsplit kernel and the oracle for every S, on ragged shapes too."""
+    from pseudo_speaker_vae_amd import _ffi
+    p = O.init_params(D, Z, 11)
+    torch.manual_seed(B)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    results = {}
+    try:
+        for S in (1, 2, 3, 4):
+            assert _ffi.lib().psvae_debug_force_wgrad_split(S) == 0
+            ws = ops.Workspace(B, D, Z, DEV)
+            grads = [torch.full_like(t, float("nan")) for t in params]
+            loss3 = torch.full((3,), float("nan"), device=DEV)
+            ops.train_step(ws, x.to(DEV), params, grads, ws.new_outputs(), loss3, beta=1.3, eps=eps.to(DEV))
+            torch.cuda.synchronize()
+            results[S] = ([g.cpu() for g in grads], {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS})
+    finally:
+        _ffi.lib().psvae_debug_force_wgrad_split(0)
+    assert _ffi.lib().psvae_debug_force_wgrad_split(5) == -4
+    _, ograds, _, _ = O.train_step(p, x, eps, 1.3, masks=results[1][1])
+    for S, (grads, _) in results.items():
+        for k, g, g1 in zip(O.PARAM_KEYS, grads, results[1][0]):
+            assert_close(g, g1, 5e-6, f"S={S} vs S=1 grad {k}")
+            assert_close(g, ograds[k], REL_TOL, f"S={S} vs oracle grad {k}")
+
+
+def test_autotuned_launch_plan_keeps_results(ops):
+    """psvae_tune_train_step_f32 only changes HOW the step is launched: after tuning the step still matches the
+    oracle, and the plan has one entry per GEMM launch."""
+    D, Z, B = 128, 32, 512
+    p = O.init_params(D, Z, 3)
+    torch.manual_seed(7)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    ws = ops.Workspace(B, D, Z, DEV)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    grads = [torch.full_like(t, float("nan")) for t in params]
+    outs = ws.new_outputs()
+    loss3 = torch.full((3,), float("nan"), device=DEV)
+    assert ops.describe_plan(ws) == "untuned"
+    plan = ops.tune_train_step(ws, x.to(DEV), params, grads, outs, loss3, iters=3)
+    assert plan == ops.describe_plan(ws)
+    sites = plan.split()
+    assert [s.split(":")[0] for s in sites] == ["F1", "F2", "F3", "F5", "F6", "F7", "B1", "B2", "B3", "B4", "B5", "B6"]
+    assert all(len(s.split(":")[1].split("/")) == 5 for s in sites)
+    for t in grads:
+        t.fill_(float("nan"))
+    ops.train_step(ws, x.to(DEV), params, grads, outs, loss3, beta=0.7, eps=eps.to(DEV))
+    torch.cuda.synchronize()
+    masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
+    losses, ograds, _, _ = O.train_step(p, x, eps, 0.7, masks=masks)
+    for i, k in enumerate(("total", "recon", "kl")):
+        assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
+    for k, g in zip(O.PARAM_KEYS, grads):
+        assert_close(g.cpu(), ograds[k], REL_TOL, "tuned step vs oracle grad " + k)
