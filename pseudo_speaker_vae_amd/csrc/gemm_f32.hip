@@ -20,6 +20,8 @@
 //     epilogue (+bias, ReLU, ReLU-mask, accumulate) applied on the way out;
 //   * one launch = a GROUP of independent problems (both encoders; a layer's wgrad + dgrad);
 //   * bias gradients (column sums of dY) come from the A fragments already in registers.
+#include <string.h>
+
 #include "psvae_common.h"
 
 namespace psvae {
@@ -250,6 +252,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     float sq = 0.f;  // EPI_BIAS_RECON: this thread's share of sum (x_hat - x)^2
     const float gsc = (epi == EPI_BIAS_RECON) ? d.scale * (d.go ? ldg<float>(d.go) : 1.0f) : 0.f;
+    const float kb = (epi == EPI_REPARAM_BWD) ? (d.go ? ldg<float>(d.go) : 1.0f) * d.scale / (float)M : 0.f;
     if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_RECON) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -305,6 +308,25 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
                 for (int e = 0; e < 4; ++e)
                     if (col + e < N) stg<float>(d.C2 + o + e, gy[e]);
             }
+        } else if (epi == EPI_REPARAM_BWD) {  // lightning.py:117-121 + model.py:57-59 differentiated; v = g_z
+            f32x4 gl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e < N) {
+                    const float gz = v[e], l = ldg<float>(d.aux2 + o + e);
+                    v[e] = gz + kb * ldg<float>(aux + o + e);
+                    gl[e] = gz * ldg<float>(d.aux3 + o + e) * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
+                } else {
+                    gl[e] = 0.f;
+                }
+            }
+            if (full) {
+                stg<f32x4>(d.C2 + o, gl);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) stg<float>(d.C2 + o + e, gl[e]);
+            }
         } else if (epi == EPI_MASK || epi == EPI_ACCUM) {
             const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
@@ -337,6 +359,32 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[w];
             stg<float>(d.partials + tm * d.tiles_n + tn, tot);
+        }
+    }
+    if (epi == EPI_REPARAM_BWD && tm == 0 && tn == 0 && ksg == 0) {
+        // one workgroup finishes the loss: KL and squared-error partial sums in fixed order (lightning.py:113-124)
+        float* __restrict__ red = smem + KS * (BM * SC) + KS * BM;
+        float kls = 0.f, rs = 0.f;
+        for (int i = tid; i < d.n_kl; i += NT) kls += ldg<float>(d.kl_part + i);
+        for (int i = tid; i < d.n_recon; i += NT) rs += ldg<float>(d.partials + i);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            kls += __shfl_xor(kls, o2);
+            rs += __shfl_xor(rs, o2);
+        }
+        __syncthreads();
+        if (lane == 0) { red[wave] = kls; red[NW + wave] = rs; }
+        __syncthreads();
+        if (tid == 0) {
+            float kt = 0.f, rt = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { kt += red[w]; rt += red[NW + w]; }
+            const float recon = rt / ((float)M * (float)d.loss_D) / 10.0f;
+            const float kl = -0.5f * kt / (float)M;
+            stg<float>(d.loss3, recon + d.scale * kl);
+            stg<float>(d.loss3 + 1, recon);
+            stg<float>(d.loss3 + 2, kl);
+            if (d.rng) d.rng[1] += d.rng_adv;
         }
     }
     if (AKM && d.colsum != nullptr && tn == 0 && tid < BM) {
@@ -435,24 +483,51 @@ static int g_forced = -1;  // -1: read PSVAE_TILE once; the tuning hook psvae_de
 void debug_force_tile(int cfg) { g_forced = cfg; }
 int num_gemm_configs() { return NCFG; }
 
-// Cost model (cycles), fitted to rocprofv3 sweeps and tools/gemm_bench.py: a workgroup occupies the 4
-// SIMDs of a CU; per-wave MFMA cycles = chunks * 4 * blocks * 32 / eff; chunks outside whole groups
-// of D run without load/MFMA overlap (x1.6); with `slots` CUs for this problem the time is about
-// max(one workgroup, per-CU share quantised to whole rounds).
-static double estimate(const GemmDesc& d, const Cfg& c, double slots) {
-    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+// Cost model (cycles), fitted to rocprofv3 sweeps and tools/gemm_bench.py.  One workgroup of config c on problem d:
+// per-wave MFMA cycles = chunks * 4 * blocks * 32 / eff, chunks outside whole groups of D without load/MFMA
+// overlap (x1.6), plus a fixed prologue/epilogue.  A launch is then list-scheduled on the 256 CUs, one
+// workgroup per CU at a time, in tile order (launch_cost).
+static double wg_cycles(const GemmDesc& d, const Cfg& c) {
     const int S = d.ksplit > 1 ? d.ksplit : 1;
-    const long t = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * S;
     const int chunks = ((d.K + 15) / 16 + S - 1) / S;
     const int per = (chunks + c.KS - 1) / c.KS;
     const int full = per / c.D * c.D, rem = per - full;
     double per_chunk = 4.0 * c.TM * c.TN * 32.0 / c.eff;
     if (d.kind == GK_NT) per_chunk *= 1.25;  // both operands k-contiguous: half-used 128-B lines per load
-    const double cyc = full * per_chunk + rem * per_chunk * 1.6 + 2200.0 + 150.0 * c.KS;
-    if (slots < 1.0) slots = 1.0;
-    const double rounds = ceil((double)t / slots);
-    const double share = cyc * rounds;
-    return share > cyc ? share : cyc;
+    if (d.kind == GK_TN) per_chunk *= 0.9;   // both operands k-major: whole lines, fewest address-unit cycles
+    return full * per_chunk + rem * per_chunk * 1.6 + 2200.0 + 150.0 * c.KS;
+}
+static long wg_count(const GemmDesc& d, const Cfg& c) {
+    const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+    const int S = d.ksplit > 1 ? d.ksplit : 1;
+    return (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * S;
+}
+// makespan of the launch with config c_tn on the TN problems and c_other on the rest: workgroups are dispatched in
+// tile order, each to the CU that frees first (one workgroup per CU at a time)
+static double launch_cost(const GemmBatch& b, int c_tn, int c_other) {
+    double free_at[256], tmp[256];  // kept ascending
+    for (int i = 0; i < 256; ++i) free_at[i] = 0.0;
+    for (int i = 0; i < b.n; ++i) {
+        const GemmDesc& d = b.d[i];
+        const Cfg& c = kCfgs[(d.kind == GK_TN ? c_tn : c_other) - 1];
+        const double cyc = wg_cycles(d, c);
+        long n = wg_count(d, c);
+        if (n > 256 * 8) {  // many rounds: every CU gets the same share
+            const double add = (double)(n / 256) * cyc;
+            for (int x = 0; x < 256; ++x) free_at[x] += add;
+            n %= 256;
+        }
+        while (n > 0) {  // the next min(n, 256) workgroups go to the earliest-free CUs; then merge the two runs
+            const int take = n < 256 ? (int)n : 256;
+            int x = 0, y = take, o = 0;
+            while (x < take && y < 256) tmp[o++] = (free_at[x] + cyc <= free_at[y]) ? free_at[x++] + cyc : free_at[y++];
+            while (x < take) tmp[o++] = free_at[x++] + cyc;
+            while (y < 256) tmp[o++] = free_at[y++];
+            memcpy(free_at, tmp, sizeof(free_at));
+            n -= take;
+        }
+    }
+    return free_at[255];
 }
 
 int pick_tile(const GemmBatch& b) {  // config of the first problem (test hook semantics)
@@ -461,7 +536,8 @@ int pick_tile(const GemmBatch& b) {  // config of the first problem (test hook s
     return c.d[0].cfg;
 }
 
-static const int kTnCands[] = {1, 8};              // wgrad: small tiles, k split 4 (a tuned plan may also pick 2 or 6)
+static const int kTnCands[] = {1, 2, 8};           // wgrad: small tiles, k split 4 (a tuned plan may also pick 6)
+constexpr int NTN = 3, NOTHER = 5;
 static const int kOtherCands[] = {1, 2, 4, 6, 8};  // forward / dgrad
 
 // cfg == 0: choose one config for the TN problems and one for the others; else force `cfg` everywhere
@@ -476,26 +552,16 @@ void finalize_batch(GemmBatch& b, int cfg) {
     int pick_tn = cfg, pick_other = cfg;
     static const int force_tn = env_int("PSVAE_CFG_TN", 0), force_other = env_int("PSVAE_CFG_OTHER", 0);  // tuning
     if (cfg == 0) {
-        // each class gets its FLOP share of the 256 CUs (at least 32: small problems ride in the
-        // others' tails); within a class the slowest problem decides
-        for (int cls = 0; cls < 2; ++cls) {
-            const int* cands = cls ? kOtherCands : kTnCands;
-            const int ncand = cls ? 5 : 2;
-            double best = 1e30;
-            int pick = cands[0];
-            for (int k = 0; k < ncand; ++k) {
-                double worst = 0;
-                for (int i = 0; i < b.n; ++i) {
-                    if ((b.d[i].kind == GK_TN) != (cls == 0)) continue;
-                    double slots = 256.0 * flops[i] / tot;
-                    if (slots < 32.0) slots = 32.0;
-                    const double e = estimate(b.d[i], kCfgs[cands[k] - 1], slots);
-                    worst = e > worst ? e : worst;
-                }
-                if (worst < best) { best = worst; pick = cands[k]; }
+        // joint choice: the pair (TN config, config of the others) with the smallest modelled makespan
+        bool has_tn = false, has_other = false;
+        for (int i = 0; i < b.n; ++i) (b.d[i].kind == GK_TN ? has_tn : has_other) = true;
+        double best = 1e30;
+        for (int a = 0; a < (has_tn ? NTN : 1); ++a)
+            for (int o = 0; o < (has_other ? NOTHER : 1); ++o) {
+                const int ct = has_tn ? kTnCands[a] : kOtherCands[o], co = has_other ? kOtherCands[o] : ct;
+                const double e = launch_cost(b, ct, co);
+                if (e < best) { best = e; pick_tn = ct; pick_other = co; }
             }
-            (cls ? pick_other : pick_tn) = pick;
-        }
         if (force_tn > 0 && force_tn <= NCFG) pick_tn = force_tn;
         if (force_other > 0 && force_other <= NCFG) pick_other = force_other;
         if (b.hint_tn > 0 && b.hint_tn <= NCFG) pick_tn = b.hint_tn;  // a tuned plan wins
@@ -521,7 +587,7 @@ void finalize_batch(GemmBatch& b, int cfg) {
 
 static size_t lds_bytes(const Cfg& c) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
-    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 8) * sizeof(float);
+    return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 16) * sizeof(float);
 }
 
 template <int C0, int C1>
@@ -557,7 +623,9 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     // than half the CU's LDS to keep one workgroup per CU.
     static const int lds_min = env_int("PSVAE_LDS_MIN", 0);  // tuning
     if ((size_t)lds_min > lds) lds = lds_min;
-    if (b.hint_cap == 1 && lds < 82 * 1024) lds = 82 * 1024;
+    static const int cap_default = env_int("PSVAE_CAP_DEFAULT", 1);  // untuned launches with more workgroups than CUs
+    const bool cap = b.hint_cap == 1 || (b.hint_cap == 0 && cap_default && b.total_tiles > 256);
+    if (cap && lds < 82 * 1024) lds = 82 * 1024;
 #define PSVAE_PAIR(A, B) if (c0 == A && c1 == B) return launch_pair<A, B>(b, lds, stream)
     PSVAE_PAIR(1, 1); PSVAE_PAIR(2, 2); PSVAE_PAIR(3, 3); PSVAE_PAIR(4, 4); PSVAE_PAIR(5, 5);
     PSVAE_PAIR(6, 6); PSVAE_PAIR(7, 7); PSVAE_PAIR(8, 8); PSVAE_PAIR(9, 9);

@@ -478,12 +478,25 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         {
             GemmBatch b{};
             add(b, wgrad(8, 6, H, Z, sc.dd1, acts->z));
-            add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
+            // g_z = dd1 W never reaches memory: the epilogue turns it into g_mu / g_logvar (reparameterisation +
+            // KL gradient), and its first workgroup finishes the loss and advances the Philox state
+            GemmDesc d = make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gmu, Z, EPI_REPARAM_BWD, mu);
+            d.aux2 = logvar;
+            d.aux3 = acts->eps;
+            d.C2 = sc.glv;
+            d.go = grad_loss;
+            d.scale = beta;
+            d.kl_part = sc.kl_partials;
+            d.n_kl = n_kl;
+            d.partials = sc.recon_partials;
+            d.n_recon = n_recon;
+            d.loss_D = D;
+            d.loss3 = loss3;
+            d.rng = eps_in ? nullptr : reinterpret_cast<unsigned long long*>(rng_state);
+            d.rng_adv = (unsigned long long)(((int64_t)B * Z + 3) / 4);
+            add(b, d);
             RET_IF(launch(b, 8));
         }
-        RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, acts->eps, beta, grad_loss, sc.gmu, sc.glv, B, Z, D,
-                                        sc.kl_partials, n_kl, sc.recon_partials, n_recon, loss3,
-                                        eps_in ? nullptr : rng_state, s));
         if (!(phases & PSVAE_PHASE_ENCODER)) {  // a decoder-only call must leave the decoder gradients complete
             RET_IF(wg.reduce(s));
         }

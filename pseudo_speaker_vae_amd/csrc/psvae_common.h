@@ -22,6 +22,7 @@ enum GemmEpi {
     EPI_MASK = 3,       // C = acc * (mask[row][col] > 0)     (ReLU backward, mask = saved activation)
     EPI_ACCUM = 4,      // C += acc                            (second dgrad into the same buffer)
     EPI_BIAS_RECON = 5, // C = acc + bias; C2 = scale*go*(C - aux2); partials[tile] = sum (C - aux2)^2
+    EPI_REPARAM_BWD = 6, // acc = g_z: C = g_mu, C2 = g_logvar of reparameterisation + KL (see GemmDesc); loss finalize
                         // (decoder output + MSE gradient + MSE partial sums, lightning.py:113)
 };
 
@@ -39,6 +40,14 @@ struct GemmDesc {
     const float* go;       // EPI_BIAS_RECON: device scalar multiplying the gradient (nullable = 1)
     float* partials;       // EPI_BIAS_RECON: one partial sum per workgroup tile of this problem
     float scale;
+    // EPI_REPARAM_BWD (fused step): aux = mu, aux2 = log-variance, aux3 = eps, C = g_mu, C2 = g_logvar, scale = beta;
+    // the workgroup of tile (0, 0) also finishes the loss from the partial sums and advances the Philox state
+    const float* aux3;
+    const float* kl_part;   // n_kl partial sums of (1 + lv - mu^2 - e^lv)
+    float* loss3;           // {total, recon, kl}
+    unsigned long long* rng;     // nullable: rng[1] += rng_adv
+    unsigned long long rng_adv;
+    int n_kl, n_recon, loss_D;  // `partials` holds the n_recon squared-error partial sums; loss_D = input dim
     int M, N, K;
     int lda, ldb, ldc;
     int kind, epi;
@@ -88,6 +97,8 @@ inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda
     d.ctab = nullptr; d.gender = nullptr; d.age = nullptr;
     d.aux2 = nullptr; d.C2 = nullptr; d.go = nullptr; d.partials = nullptr; d.scale = 1.f;
     d.ksplit = 1;
+    d.aux3 = nullptr; d.kl_part = nullptr; d.loss3 = nullptr; d.rng = nullptr; d.rng_adv = 0;
+    d.n_kl = 0; d.n_recon = 0; d.loss_D = 0;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.kind = kind; d.epi = epi;
     return d;
 }
@@ -110,6 +121,14 @@ struct GemmDescBf {
     const int32_t* gender;
     const int32_t* age;
     float scale;
+    // EPI_REPARAM_BWD (fused step): aux = mu, aux2 = log-variance, aux3 = eps, C = g_mu, C2 = g_logvar, scale = beta;
+    // the workgroup of tile (0, 0) also finishes the loss from the partial sums and advances the Philox state
+    const float* aux3;
+    const float* kl_part;   // n_kl partial sums of (1 + lv - mu^2 - e^lv)
+    float* loss3;           // {total, recon, kl}
+    unsigned long long* rng;     // nullable: rng[1] += rng_adv
+    unsigned long long rng_adv;
+    int n_kl, n_recon, loss_D;  // `partials` holds the n_recon squared-error partial sums; loss_D = input dim
     int M, N, K;                 // K % 32 == 0
     int lda, ldb, ldcf, ldcb, ldt, ldmask;
     int epi;
