@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1_000_000, help="decode workload: rows over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="skip the launch-plan autotuning (heuristic configs)")
+    ap.add_argument("--plan", default="", help="use this launch plan (text form printed as config.launch_plan)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,7 +181,9 @@ def main():
         eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
 
     plan = "untuned"
-    if not args.no_tune:
+    if args.plan:
+        plan = eng.tune(x, plan=args.plan)  # a plan tuned by an earlier run (profiling runs reuse the bench's)
+    elif not args.no_tune:
         plan = eng.tune(x)  # launch-plan autotuning, once per shape, outside the timed region
     mode = args.mode
     if mode == "auto":

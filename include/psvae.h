@@ -149,6 +149,8 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
                               const psvae_grads* grads, float* loss3, void* scratch, int iters, void* stream);
 /* text form of the plan in use for (B, D, Z) ("untuned" if none) */
 int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n);
+/* install a plan from that text form ("untuned" removes it); PSVAE_ERR_ARG if it does not parse */
+int psvae_set_plan(const psvae_dims* dims, const char* text);
 
 /* bf16 variant of psvae_train_step_f32 (BASELINE config 3: bf16 MFMA operands, fp32 accumulate, fp32 master
  * weights, gradients and loss).  D and Z must be multiples of 32.  x, params, grads, outputs, eps_out[B,Z] and

@@ -27,7 +27,7 @@ ABI_VERSION = 1
 SYMBOLS = (
     "psvae_version", "psvae_debug_force_tile", "psvae_debug_force_wgrad_split", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
-    "psvae_tune_train_step_f32", "psvae_describe_plan",
+    "psvae_tune_train_step_f32", "psvae_describe_plan", "psvae_set_plan",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
 )
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.psvae_tune_train_step_f32.restype = C.c_int
     L.psvae_describe_plan.argtypes = [C.POINTER(Dims), C.c_char_p, C.c_size_t]
     L.psvae_describe_plan.restype = C.c_int
+    L.psvae_set_plan.argtypes = [C.POINTER(Dims), C.c_char_p]
+    L.psvae_set_plan.restype = C.c_int
     L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
                                        vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_bf16_scratch_bytes.restype = C.c_size_t

@@ -598,6 +598,37 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     return 0;
 }
 
+// install a plan from its text form (psvae_describe_plan's output; "untuned" removes it) -- lets a profiling run
+// or a later process reuse a plan tuned elsewhere on the same GPU model
+int psvae_set_plan(const psvae_dims* dims, const char* text) {
+    if (int e = check_dims(dims)) return e;
+    if (!text) return PSVAE_ERR_NULL;
+    const auto key = std::make_tuple(dims->B, dims->D, dims->Z);
+    if (strcmp(text, "untuned") == 0) {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        g_plans.erase(key);
+        return 0;
+    }
+    StepPlan p{};
+    const char* c = text;
+    for (int i = 0; i < NSITE; ++i) {
+        while (*c == ' ') ++c;
+        const char* colon = strchr(c, ':');
+        if (!colon) return PSVAE_ERR_ARG;
+        int v[5];
+        if (sscanf(colon + 1, "%d/%d/%d/%d/%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5) return PSVAE_ERR_ARG;
+        if (v[0] < 0 || v[0] > num_gemm_configs() || v[1] < 0 || v[1] > num_gemm_configs() || v[2] < 0 ||
+            v[2] > WGRAD_SMAX || v[3] < 0 || v[3] > 2 || v[4] < 0 || v[4] > 2)
+            return PSVAE_ERR_ARG;
+        p.site[i] = SitePlan{(signed char)v[0], (signed char)v[1], (signed char)v[2], (signed char)v[3], (signed char)v[4]};
+        c = strchr(colon, ' ');
+        if (!c) { if (i != NSITE - 1) return PSVAE_ERR_ARG; break; }
+    }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans[key] = p;
+    return 0;
+}
+
 // text form of the plan in use for (B, D, Z): "site:tn/other/ksplit/cap/remap ..." ("untuned" if none)
 int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n) {
     if (int e = check_dims(dims)) return e;

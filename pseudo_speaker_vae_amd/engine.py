@@ -165,12 +165,15 @@ class TrainEngine:
         self.averager.reduce_bucket(0)                 # encoder grads + the 3 loss scalars
         self.averager.wait()
 
-    def tune(self, x: torch.Tensor, iters: int = 10) -> str:
+    def tune(self, x: torch.Tensor, iters: int = 10, plan: Optional[str] = None) -> str:
         """Autotune the fused step's launch plan for this batch shape (fp32, default loss, unconditional only;
         a no-op otherwise).  Takes a few seconds once; later steps -- eager or captured -- use the plan.  Gradients,
         outputs and the loss buffer are overwritten.  Returns the plan's text form."""
         if self.dtype != "f32" or self.flags != 0 or self.conditional:
             return "untuned"
+        if plan is not None:  # reuse a plan tuned earlier (text form) instead of measuring
+            ops.set_plan(self.ws, plan)
+            return ops.describe_plan(self.ws)
         return ops.tune_train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters)
 
     def set_labels(self, gender: torch.Tensor, age: torch.Tensor):

@@ -152,6 +152,11 @@ def describe_plan(ws: Workspace) -> str:
     return buf.value.decode()
 
 
+def set_plan(ws: Workspace, text: str) -> None:
+    """install a launch plan from describe_plan's text form ("untuned" removes it)"""
+    _ffi.check(_ffi.lib().psvae_set_plan(C.byref(ws.dims), text.encode()), "set_plan")
+
+
 class Bf16Workspace:
     """buffers of one batch shape for the bf16 training pass (scratch is zero-filled once: see psvae.h)"""
 
