@@ -36,7 +36,10 @@ __device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even, NaN pr
 }
 __device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned)u) << 16); }
 
-template <int TM, int TN, int WM, int WN, int KS, int D>
+// STAGED: the 128x128 tile's operand panels go through LDS (each element fetched once per workgroup, whole 128-B
+// lines per 8 lanes) instead of every wave fetching its own fragments -- at these sizes the bf16 GEMMs are pure
+// operand traffic (the MFMAs of a 2-GFLOP launch take 1 us), so bytes per workgroup decide the time.
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED>
 __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int tn, float* __restrict__ smem) {
     constexpr int NW = WM * WN * KS;
     static_assert(NW == 4, "4 waves per workgroup");
@@ -63,6 +66,74 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     for (int m = 0; m < TM; ++m) csum[m] = 0.f;
     const bool do_colsum = (d.colsum != nullptr) && (tn == 0) && (wn == 0);
 
+    if constexpr (STAGED) {
+        static_assert(KS == 1 && WM == 2 && WN == 2 && TM == 4 && TN == 4, "staged loop: 128x128 tile, 2x2 waves");
+        constexpr int BK = 64, LS = BK + 8;  // LDS row stride in bf16: 144 B keeps ds_read_b128 of 16 rows conflict-free
+        u16* sA = reinterpret_cast<u16*>(smem);            // [2][BM][LS]
+        u16* sB = sA + 2 * BM * LS;                        // [2][BN][LS]
+        // global -> register -> LDS: 16-B pieces, 8 consecutive lanes = one 128-B line of one row
+        const int prow = tid >> 3, pk = (tid & 7) * 8;     // piece (row, k) of pass i: row = prow + 32 i
+        const u16* ga[4];
+        const u16* gb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ra = m0 + prow + 32 * i, rb = n0 + prow + 32 * i;
+            ra = ra < M ? ra : M - 1;  // clamped rows only feed outputs the epilogue never stores
+            rb = rb < N ? rb : N - 1;
+            ga[i] = A + (size_t)ra * d.lda + pk;
+            gb[i] = B + (size_t)rb * d.ldb + pk;
+        }
+        bf16x8 ra_[4], rb_[4];
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto gload = [&](int t) {
+            const int k0 = t * BK;
+            const bool in = k0 + pk < K;  // K % 32 == 0: the last tile may hold only its first half
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra_[i] = in ? ldgb<bf16x8>(ga[i] + k0) : zero8;
+                rb_[i] = in ? ldgb<bf16x8>(gb[i] + k0) : zero8;
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<bf16x8*>(sA + (buf * BM + prow + 32 * i) * LS + pk) = ra_[i];
+                *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[i];
+            }
+        };
+        const int nt = (K + BK - 1) / BK;
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) gload(t + 1);  // in flight under this tile's MFMAs
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 32; ++s2) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+                    fa[m] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + wm * 64 + 16 * m + r) * LS + 32 * s2 + 8 * q);
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    fb[n] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + wn * 64 + 16 * n + r) * LS + 32 * s2 + 8 * q);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                if (do_colsum) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) csum[m] += bf2f((u16)fa[m][e]);
+                }
+            }
+            if (t + 1 < nt) lstore(buf ^ 1);  // the other buffer: last read before the previous barrier
+            __syncthreads();
+        }
+        // (the loop's last barrier also fences the staging buffers against the epilogue's reuse of this LDS)
+    } else {
     // row pointers (rows clamped: they only feed outputs the epilogue never stores)
     const u16* pa[TM];
     const u16* pb[TN];
@@ -103,18 +174,24 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                 for (int e = 0; e < 8; ++e) csum[m] += bf2f((u16)fa[s][m][e]);
         }
     };
+    // software pipeline over a ring of D fragment slots, pinned with sched_barriers (see gemm_f32.hip: left alone the
+    // compiler sinks all loads of a group below its last MFMA)
     int c = cbeg;
     const int nfull = cend > cbeg ? (cend - cbeg) / D : 0;
     if (nfull > 0) {
 #pragma unroll
-        for (int s = 0; s < D; ++s) load(s, cbeg + s);
-        for (int g = 1; g < nfull; ++g) {
+        for (int s = 0; s < D - 1; ++s) load(s, cbeg + s);
+        for (int g = 0; g < nfull - 1; ++g) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
+                load((s + D - 1) % D, cbeg + g * D + s + D - 1);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(s);
-                load(s, cbeg + g * D + s);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        load(D - 1, cbeg + nfull * D - 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < D; ++s) mma(s);
         c = cbeg + nfull * D;
@@ -126,6 +203,8 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
 #pragma unroll
         for (int s = 0; s < D; ++s)
             if (c + s < cend) mma(s);
+    }
+
     }
 
     // ---- epilogue ----
@@ -161,6 +240,15 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         for (int e = 0; e < 4; ++e)
             if (col + e < N) bias4[e] = ldgb<float>(d.bias + col + e);
     }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ct[6] = {zero4, zero4, zero4, zero4, zero4, zero4};  // this thread's 4 columns of the conditional table
+    if (d.ctab) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < N) ct[c][e] = ldgb<float>(d.ctab + (size_t)c * N + col + e);
+    }
     float sq = 0.f;
     const float gsc = (epi == BEPI_RECON) ? d.scale * (d.go ? ldgb<float>(d.go) : 1.0f) : 0.f;
     const bool colfull = col + 3 < N;
@@ -174,15 +262,10 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 4 * c4);
         if (row < M && col < N) {
             v += bias4;
-            if (d.ctab) {
+            if (d.ctab) {  // one-hot conditioning: + table[gender] + table[3 + age], table columns preloaded above
                 const int g = d.gender[row], a = d.age[row];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (col + e < N) {
-                        if (g >= 0 && g < 3) v[e] += ldgb<float>(d.ctab + (size_t)g * N + col + e);
-                        if (a >= 0 && a < 3) v[e] += ldgb<float>(d.ctab + (size_t)(3 + a) * N + col + e);
-                    }
-                }
+                v += (g == 0 ? ct[0] : g == 1 ? ct[1] : g == 2 ? ct[2] : zero4);
+                v += (a == 0 ? ct[3] : a == 1 ? ct[4] : a == 2 ? ct[5] : zero4);
             }
             if (epi == BEPI_RELU) {
 #pragma unroll
@@ -211,9 +294,18 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                 }
             }
             if (epi == BEPI_RECON) {  // v = x_hat: emit the MSE gradient instead of v into the bf16 outputs
+                const float* tp = d.target + (size_t)row * d.ldcf + col;
+                f32x4 xt = zero4;
+                if (colfull && ((d.ldcf & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.target) & 15) == 0)) {
+                    xt = ldgb<f32x4>(tp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) xt[e] = ldgb<float>(tp + e);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float df = (col + e < N) ? v[e] - ldgb<float>(d.target + (size_t)row * d.ldcf + col + e) : 0.f;
+                    const float df = (col + e < N) ? v[e] - xt[e] : 0.f;
                     sq += df * df;
                     v[e] = gsc * df;
                 }
@@ -238,9 +330,16 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     }
     if (d.CbT) {  // transposed bf16 copy [N][ldt]: column reads of the finished tile, 4 rows per lane
         __syncthreads();
-        constexpr int MQ = BM / 4;
+        constexpr int MQ = BM / 4;            // row quads
+        constexpr int QW = MQ >= 8 ? 8 : MQ;  // quads per 64-item block (BM = 16: 4)
+        constexpr int CW = 64 / QW;           // columns per block (BN is a multiple)
+        constexpr int QB = MQ / QW;
+        static_assert(BN % CW == 0 && MQ % QW == 0, "tile shape vs transposed-store blocks");
         for (int i = tid; i < BN * MQ; i += NT) {
-            const int n = i / MQ, mq = i % MQ;
+            // lane order inside 64 items: QW consecutive row quads (64-B contiguous stores) x CW consecutive columns
+            // (LDS banks 16*mq + n: at most 2-way conflicts, the plain n-major order was 8-way)
+            const int blk = i >> 6, l = i & 63;
+            const int mq = (blk % QB) * QW + (l % QW), n = (blk / QB) * CW + (l / QW);
             const int gn = n0 + n, gm = m0 + 4 * mq;
             if (gn >= N) continue;
             u16* p = d.CbT + (size_t)gn * d.ldt + gm;
@@ -273,7 +372,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     }
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D>
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
@@ -283,13 +382,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch)
     const GemmDescBf& d = batch.d[di];
     const int lt = tile - d.tile_begin;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    gemm_tile_bf16<TM, TN, WM, WN, KS, D>(d, tm, tn, smem);
+    gemm_tile_bf16<TM, TN, WM, WN, KS, D, STAGED>(d, tm, tn, smem);
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D>
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED = false>
 static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
     constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
-    constexpr size_t lds = (size_t)(KS * BM * (BN + 4) + KS * BM + 8) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)(KS * BM * (BN + 4) + KS * BM + 8) * sizeof(float);
+    constexpr size_t lds_stage = STAGED ? (size_t)2 * (BM + BN) * (64 + 8) * 2 : 0;  // two buffers of A and B panels
+    constexpr size_t lds = lds_epi > lds_stage ? lds_epi : lds_stage;
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
         b.d[i].tiles_m = (b.d[i].M + BM - 1) / BM;
@@ -299,13 +400,18 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
     }
     b.total_tiles = t;
     static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 96 * 1024 ? lds : 96 * 1024));
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, WM, WN, KS, D>), dim3(t), dim3(256), lds, stream, b);
+    // more workgroups than CUs: one workgroup per CU at a time (co-resident workgroups thrash the shared L1, see
+    // gemm_f32.hip); the request only has to exceed half the CU's LDS
+    static const bool cap_on = getenv("PSVAE_BF16_CAP") != nullptr && atoi(getenv("PSVAE_BF16_CAP")) != 0;  // measured: slower here
+    size_t lds_req = lds;
+    if (cap_on && t > 256 && lds_req < 82 * 1024) lds_req = 82 * 1024;
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED>), dim3(t), dim3(256), lds_req, stream, b);
     return hipGetLastError();
 }
 
@@ -320,8 +426,13 @@ hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
         t22 += (long)((b.d[i].M + 31) / 32) * ((b.d[i].N + 31) / 32);
         kmax = b.d[i].K > kmax ? b.d[i].K : kmax;
     }
+    const char* bm = getenv("PSVAE_BF16_BIG_MIN");  // tuning / tests (read per call: a test flips it in-process)
+    const int big_min = bm ? atoi(bm) : 2048;
     if (t44 >= 192) {
-        if (t44 >= 2048 && kmax <= 1024) return launch_bf<4, 4, 2, 2, 1, 2>(b, stream);  // 128x128 tiles, no split
+        const char* st = getenv("PSVAE_BF16_STAGED");
+        const int staged = st ? atoi(st) : 1;
+        if (t44 >= big_min && kmax <= 1024)  // 128x128 tiles, no split
+            return staged ? launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream) : launch_bf<4, 4, 2, 2, 1, 2>(b, stream);
         return launch_bf<4, 4, 1, 1, 4, 2>(b, stream);                                    // 64x64, k split 4
     }
     if (t22 >= 128) return launch_bf<2, 2, 1, 1, 4, 4>(b, stream);                         // 32x32, k split 4

@@ -121,14 +121,6 @@ struct GemmDescBf {
     const int32_t* gender;
     const int32_t* age;
     float scale;
-    // EPI_REPARAM_BWD (fused step): aux = mu, aux2 = log-variance, aux3 = eps, C = g_mu, C2 = g_logvar, scale = beta;
-    // the workgroup of tile (0, 0) also finishes the loss from the partial sums and advances the Philox state
-    const float* aux3;
-    const float* kl_part;   // n_kl partial sums of (1 + lv - mu^2 - e^lv)
-    float* loss3;           // {total, recon, kl}
-    unsigned long long* rng;     // nullable: rng[1] += rng_adv
-    unsigned long long rng_adv;
-    int n_kl, n_recon, loss_D;  // `partials` holds the n_recon squared-error partial sums; loss_D = input dim
     int M, N, K;                 // K % 32 == 0
     int lda, ldb, ldcf, ldcb, ldt, ldmask;
     int epi;
