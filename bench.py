@@ -197,9 +197,22 @@ def main():
             if args.with_adam:
                 eng.optimizer_step()
     elif mode == "graph":
-        if pg is not None:
-            mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
-        eng.capture(x)
+        in_graph = os.environ.get("PSVAE_DDP_IN_GRAPH", "1")  # 1: one all-reduce inside the graph (default), 2: decoder
+        # bucket overlapped as a parallel graph branch (fork/join costs more than it hides at 1 rank), 0: outside
+        if pg is not None and in_graph in ("1", "2"):
+            try:
+                eng.capture_with_collective(x, overlap=(in_graph == "2"))
+                mode = "graph(all-reduce inside" + (", decoder bucket overlapped)" if in_graph == "2" else ")")
+            except Exception as e:  # the collective could not be captured: keep it outside the graph
+                if rank == 0:
+                    print(f"[bench] in-graph all-reduce unavailable ({type(e).__name__}: {e}); falling back", file=sys.stderr)
+                eng._collective_in_graph = False
+                mode = "graph+allreduce"
+                eng.capture(x)
+        else:
+            if pg is not None:
+                mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
+            eng.capture(x)
 
         def step():
             eng.replay()

@@ -214,9 +214,49 @@ class TrainEngine:
         """one captured step; with a process group: followed by ONE all-reduce of the flat gradient buffer
         (the collective itself stays outside the graph)"""
         self._graph.replay()
-        if self.averager is not None:
+        if self.averager is not None and not getattr(self, "_collective_in_graph", False):
             self.averager.reduce_all()
             self.averager.wait()
+
+    def capture_with_collective(self, x: torch.Tensor, overlap: bool = True):
+        """Data-parallel step as ONE HIP graph, RCCL all-reduce(s) included (RCCL kernels are capturable): no
+        host-side stream hand-offs per step.  overlap=True: the decoder bucket's all-reduce is a parallel branch
+        of the graph under the encoder backward (default loss only); else one all-reduce at the end.
+        Raises if the collective cannot be captured -- callers fall back to capture() + replay()."""
+        import torch.distributed as dist
+        if self.averager is None or self.averager.backend != "nccl":
+            raise _ffi.PsvaeError("capture_with_collective needs an RCCL (nccl) process group")
+        self.static_x = x.detach().clone()
+        split = overlap and self.dtype == "f32" and self.flags == 0
+        kw = dict(beta=self.beta, rng_state=self.rng_state)
+
+        def body():
+            if split:
+                ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
+                               phases=_ffi.PHASE_DECODER, **kw)
+                self.averager.reduce_bucket(1)
+                ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
+                               phases=_ffi.PHASE_ENCODER, **kw)
+                self.averager.reduce_bucket(0)
+            else:
+                self.forward_backward(self.static_x, _local_only=True)
+                self.averager.reduce_all()
+            self.averager.wait()
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm-up outside capture: communicator setup, lazy module load
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.averager.pg)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        self._graph = g
+        self._collective_in_graph = True
+        return g
 
     def capture_ddp(self, x: torch.Tensor):
         """Data-parallel variant: the step cannot be ONE graph (the RCCL all-reduces stay eager), so capture
