@@ -123,6 +123,29 @@ inline void set_cond(GemmDesc& d, const psvae_cond* c, int which) {
     d.ctab = c->tab[which];
 }
 
+// ---- tuned launch plans (12 GEMM launch sites: F1 F2 F3 F5 F6 F7 B1 B2 B3 B4 B5 B6) ------------------------
+// The fused step and the separate forward / backward entry points launch the same GEMM groups, so they share plans.
+// key (B, D, Z) -> plan; filled by psvae_tune_train_step_f32, read at every train-step call (also while a HIP
+// graph is being captured: the captured launches carry the tuned configs).
+std::mutex g_plan_mu;
+std::map<std::tuple<int64_t, int64_t, int64_t>, StepPlan> g_plans;
+const StepPlan* g_trial = nullptr;  // the tuner's candidate (single-threaded use under g_tune_mu)
+std::mutex g_tune_mu;
+
+bool find_plan(int64_t B, int64_t D, int64_t Z, StepPlan* out) {
+    if (g_trial) { *out = *g_trial; return true; }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(std::make_tuple(B, D, Z));
+    if (it == g_plans.end()) return false;
+    *out = it->second;
+    return true;
+}
+
+inline void apply_site(GemmBatch& b, const StepPlan& plan, int site) {
+    const SitePlan& sp = plan.site[site];
+    b.hint_tn = sp.cfg_tn; b.hint_other = sp.cfg_other; b.hint_cap = sp.cap; b.hint_remap = sp.remap;
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +220,8 @@ int psvae_forward_f32(const psvae_dims* dims, const float* x, const psvae_params
     hipStream_t s = (hipStream_t)stream;
     const float* const* P = params->p;
     Scratch sc = carve(scratch, B, D, Z);
+    StepPlan plan{};
+    find_plan(B, D, Z, &plan);  // a plan tuned on the fused step also serves these launches
 
     {  // encoder layer 1 (model.py:15,23): both encoders in one launch
         GemmBatch b{};
@@ -205,18 +230,21 @@ int psvae_forward_f32(const psvae_dims* dims, const float* x, const psvae_params
         set_cond(dm, cond, 0);
         set_cond(ds, cond, 1);
         add(b, dm); add(b, ds);
+        apply_site(b, plan, 0);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     {  // encoder layer 2 (model.py:17,25)
         GemmBatch b{};
         add(b, make_desc(GK_NT, B, H, H, acts->h1m, H, P[2], H, acts->h2m, H, EPI_BIAS_RELU, P[3]));
         add(b, make_desc(GK_NT, B, H, H, acts->h1s, H, P[8], H, acts->h2s, H, EPI_BIAS_RELU, P[9]));
+        apply_site(b, plan, 1);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     {  // encoder layer 3 -> mu, logvar (model.py:19,27)
         GemmBatch b{};
         add(b, make_desc(GK_NT, B, Z, H, acts->h2m, H, P[4], H, mu, Z, EPI_BIAS, P[5]));
         add(b, make_desc(GK_NT, B, Z, H, acts->h2s, H, P[10], H, logvar, Z, EPI_BIAS, P[11]));
+        apply_site(b, plan, 2);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     // reparameterise (model.py:56-57)
@@ -226,16 +254,19 @@ int psvae_forward_f32(const psvae_dims* dims, const float* x, const psvae_params
         GemmDesc d1 = make_desc(GK_NT, B, H, Z, acts->z, Z, P[12], Z, acts->d1, H, EPI_BIAS_RELU, P[13]);
         set_cond(d1, cond, 2);
         add(b, d1);
+        apply_site(b, plan, 3);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     {
         GemmBatch b{};
         add(b, make_desc(GK_NT, B, H, H, acts->d1, H, P[14], H, acts->d2, H, EPI_BIAS_RELU, P[15]));
+        apply_site(b, plan, 4);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     {
         GemmBatch b{};
         add(b, make_desc(GK_NT, B, D, H, acts->d2, H, P[16], H, normalize ? sc.y : x_hat, D, EPI_BIAS, P[17]));
+        apply_site(b, plan, 5);
         RET_IF(launch_gemm_batch(b, 0, s));
     }
     if (normalize) RET_IF(launch_normalize_rows(sc.y, x_hat, acts->ynorm, B, D, s));  // model.py:60-61
@@ -273,6 +304,8 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
     float* const* G = grads->g;
     Scratch sc = carve(scratch, B, D, Z);
     WgradPlan wg(B, sc, G);
+    StepPlan plan{};
+    find_plan(B, D, Z, &plan);
 
     if (phases & PSVAE_PHASE_DECODER) {
         const float* gy;
@@ -287,18 +320,21 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             GemmBatch b{};
             add(b, wg.desc(8, D, H, gy, acts->d2));
             add(b, make_desc(GK_NN, B, H, D, gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
+            apply_site(b, plan, 6);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // decoder.2
             GemmBatch b{};
             add(b, wg.desc(7, H, H, sc.dd2, acts->d1));
             add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
+            apply_site(b, plan, 7);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // decoder.0: dW = dd1^T z ; g_z = dd1 W
             GemmBatch b{};
             add(b, wg.desc(6, H, Z, sc.dd1, acts->z));
             add(b, make_desc(GK_NN, B, Z, H, sc.dd1, H, P[12], Z, sc.gz, Z, EPI_NONE, nullptr));
+            apply_site(b, plan, 8);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         RET_IF(launch_reparam_bwd(sc.gz, mu, logvar, acts->eps, g_mu, g_logvar, elbo, beta, grad_loss, sc.gmu, sc.glv,
@@ -317,6 +353,7 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             add(b, wg.desc(5, Z, H, sc.glv, acts->h2s));
             add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
             add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
+            apply_site(b, plan, 9);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // encoder_*.2
@@ -325,12 +362,14 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
             add(b, wg.desc(4, H, H, sc.dh2s, acts->h1s));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
+            apply_site(b, plan, 10);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         {  // encoder_*.0 (x needs no gradient in the reference: no dgrad)
             GemmBatch b{};
             add(b, wg.desc(0, H, D, sc.dh1m, x));
             add(b, wg.desc(3, H, D, sc.dh1s, x));
+            apply_site(b, plan, 11);
             RET_IF(launch_gemm_batch(b, 0, s));
         }
         if (has_cond) {
@@ -349,23 +388,6 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
         }
     }
     return 0;
-}
-
-// ---- tuned launch plans of the fused step -----------------------------------------------------------
-// key (B, D, Z) -> plan; filled by psvae_tune_train_step_f32, read at every train-step call (also while a HIP
-// graph is being captured: the captured launches carry the tuned configs).
-static std::mutex g_plan_mu;
-static std::map<std::tuple<int64_t, int64_t, int64_t>, StepPlan> g_plans;
-static const StepPlan* g_trial = nullptr;  // the tuner's candidate (single-threaded use under g_tune_mu)
-static std::mutex g_tune_mu;
-
-static bool find_plan(int64_t B, int64_t D, int64_t Z, StepPlan* out) {
-    if (g_trial) { *out = *g_trial; return true; }
-    std::lock_guard<std::mutex> lk(g_plan_mu);
-    auto it = g_plans.find(std::make_tuple(B, D, Z));
-    if (it == g_plans.end()) return false;
-    *out = it->second;
-    return true;
 }
 
 // forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs:
@@ -401,8 +423,7 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
                         : make_desc(GK_NT, B, N, K, X, K, P[2 * wk], K, Y, N, epi, P[2 * wk + 1]);
     };
     auto launch = [&](GemmBatch& b, int site) {
-        const SitePlan& sp = plan.site[site];
-        b.hint_tn = sp.cfg_tn; b.hint_other = sp.cfg_other; b.hint_cap = sp.cap; b.hint_remap = sp.remap;
+        apply_site(b, plan, site);
         return launch_gemm_batch(b, 0, s);
     };
     WgradPlan wg(B, sc, G);

@@ -239,6 +239,19 @@ class VAEModel(nn.Module):
         """model.py:65-69."""
         return DecodeFunction.apply(z, self.flags, *self.ordered_params()[12:])
 
+    def tune(self, batch_size: int, iters: int = 10) -> str:
+        """Optional, once per batch size: autotune the GEMM launch plan for (batch_size, input_dim, latent_dim)
+        (`psvae_tune_train_step_f32`, a few seconds on scratch buffers).  `forward` / `elbo_step` / their backward
+        then launch with the tuned plan.  Returns the plan's text form."""
+        from . import ops
+        p0 = self.encoder_mu[0].weight
+        ws = ops.Workspace(batch_size, self.input_dim, self.latent_dim, p0.device)
+        params = [t.detach() for t in self.ordered_params()]
+        grads = [torch.empty_like(t) for t in params]
+        x = torch.randn(batch_size, self.input_dim, device=p0.device)
+        loss3 = torch.empty(3, device=p0.device)
+        return ops.tune_train_step(ws, x, params, grads, ws.new_outputs(), loss3, iters=iters)
+
     def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
                   eps: Optional[torch.Tensor] = None):
         """fused forward + ELBO (lightning.py:110-124): returns (total, recon, kl, x_hat, mu, logvar)."""

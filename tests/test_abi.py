@@ -52,3 +52,23 @@ def test_cpu_tensors_are_refused_loudly():
     from pseudo_speaker_vae_amd import _ffi, ops
     with pytest.raises(_ffi.PsvaeError, match="no CPU path"):
         ops.gemm(0, torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_launch_plan_text_roundtrip_and_errors(lib):
+    """psvae_set_plan / psvae_describe_plan are host-only: a plan survives the text round trip, garbage is refused."""
+    from pseudo_speaker_vae_amd import _ffi
+    d = _ffi.Dims(777, 256, 64)
+    buf = C.create_string_buffer(1024)
+    assert lib.psvae_describe_plan(C.byref(d), buf, 1024) == 0 and buf.value == b"untuned"
+    plan = b"F1:0/6/0/1/1 F2:0/2/0/2/2 F3:0/8/0/0/0 F5:0/4/0/2/1 F6:0/0/0/0/0 F7:0/1/0/1/2 " \
+           b"B1:2/6/2/2/2 B2:1/6/1/1/1 B3:8/8/4/2/1 B4:8/1/1/2/2 B5:6/6/1/1/1 B6:1/1/1/2/1"
+    assert lib.psvae_set_plan(C.byref(d), plan) == 0
+    assert lib.psvae_describe_plan(C.byref(d), buf, 1024) == 0 and buf.value == plan
+    other = _ffi.Dims(778, 256, 64)  # plans are per (B, D, Z)
+    assert lib.psvae_describe_plan(C.byref(other), buf, 1024) == 0 and buf.value == b"untuned"
+    for bad in (b"F1:0/6/0/1", b"nonsense", b"F1:0/99/0/1/1 " + plan[13:], plan.replace(b"B3:8/8/4", b"B3:8/8/9")):
+        assert lib.psvae_set_plan(C.byref(d), bad) == -4, bad
+    assert lib.psvae_set_plan(C.byref(d), None) == -1
+    assert lib.psvae_set_plan(C.byref(d), b"untuned") == 0
+    assert lib.psvae_describe_plan(C.byref(d), buf, 1024) == 0 and buf.value == b"untuned"
+    assert lib.psvae_tune_train_step_f32(C.byref(d), None, None, None, None, None, None, None, None, None, 0, None) == -4

@@ -284,3 +284,26 @@ def test_packed_embedding_table_gather():
     assert torch.equal(allx.sum(0), emb[torch.randperm(N, generator=torch.Generator().manual_seed(1))].sum(0))
     odd = PackedEmbeddingTable(torch.randn(10, 30), device=DEV)  # D % 4 != 0: scalar path
     assert torch.equal(odd.batch(torch.tensor([3, 9])).cpu(), odd.table[[3, 9]].cpu())
+
+
+def test_model_tune_then_training_step_still_matches_oracle():
+    """VAEModel.tune installs a launch plan for its shape; the autograd path (separate forward / backward entry
+    points, which share the plan) still matches the oracle."""
+    import torch
+    from oracle import psvae_oracle as O
+    from pseudo_speaker_vae_amd.model import VAEModel
+    from helpers import assert_close, REL_TOL
+    D, Z, B = 128, 32, 256
+    m = VAEModel(D, Z).to("cuda:0")
+    plan = m.tune(B, iters=2)
+    assert plan.startswith("F1:")
+    p = {k: v.detach().cpu() for k, v in zip(O.PARAM_KEYS, m.ordered_params())}
+    torch.manual_seed(3)
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    total, recon, kl, xh, mu, lv = m.elbo_step(x.cuda(), beta=0.8, eps=eps.cuda())
+    total.backward()
+    losses, ograds, acts, _ = O.train_step(p, x, eps, 0.8)
+    assert abs(float(total) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
+    assert_close(xh.detach().cpu(), acts["x_hat"], REL_TOL, "x_hat")
+    for k, t in zip(O.PARAM_KEYS, m.ordered_params()):
+        assert_close(t.grad.cpu(), ograds[k], 5e-4, "grad " + k)  # no mask alignment here: allow a ReLU-kink flip
