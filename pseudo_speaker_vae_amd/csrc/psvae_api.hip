@@ -68,7 +68,10 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
     s.dh1m = take((size_t)B * H);
     s.dh1s = take((size_t)B * H);
     s.partials = take(2 * 1024);
-    s.kl_partials = take((size_t)reparam_blocks(B * Z));
+    {  // KL partial sums: one per block of the reparam kernel or one per row tile of the fused bottleneck kernel
+        const size_t blocks = (size_t)reparam_blocks(B * Z), tiles = (size_t)reparam_linear_tiles((int)B);
+        s.kl_partials = take(blocks > tiles ? blocks : tiles);
+    }
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));  // smallest GEMM tile is 16 x 32
     s.recon_partials = take((size_t)s.n_recon_max);
     {
@@ -411,7 +414,7 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     const float* const* P = params->p;
     float* const* G = grads->g;
     Scratch sc = carve(scratch, B, D, Z);
-    const int n_kl = reparam_blocks((int64_t)B * Z);
+    int n_kl = reparam_blocks((int64_t)B * Z);
     StepPlan plan{};
     find_plan(B, D, Z, &plan);  // all-zero (heuristics) when this shape was never tuned
 
@@ -458,9 +461,16 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             add(b, fwd(acts->h2s, H, 5, Z, logvar, EPI_BIAS));
             RET_IF(launch(b, 2));
         }
-        RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
-                                 (int64_t)B * Z, s));
-        {
+        const void* al[] = {mu, logvar, eps_in, acts->eps, acts->z, acts->d1, P[12], P[13]};
+        static const bool bottleneck_on = getenv("PSVAE_NO_BOTTLENECK") == nullptr;
+        if (bottleneck_on && reparam_linear_ok(Z, H, al, 8)) {
+            // reparameterisation + KL partials + decoder layer 0 (K = Z) as one dedicated launch
+            RET_IF(launch_reparam_linear(mu, logvar, eps_in, rng_state, seed, offset, P[12], P[13], acts->eps, acts->z,
+                                         acts->d1, sc.kl_partials, B, Z, H, s));
+            n_kl = reparam_linear_tiles(B);
+        } else {
+            RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
+                                     (int64_t)B * Z, s));
             GemmBatch b{};
             add(b, fwd(acts->z, Z, 6, H, acts->d1, EPI_BIAS_RELU));
             RET_IF(launch(b, 3));

@@ -147,6 +147,13 @@ hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in,
 // fused-step variant: also writes one KL partial sum per block (kl_partials[reparam_blocks(n)]) and
 // leaves the rng advance to launch_reparam_bwd_final
 int reparam_blocks(int64_t n);
+// reparameterisation + KL partials + decoder layer 0 in one launch (Z % 16 == 0, Z <= 128, N % 4 == 0, 16-B aligned
+// pointers); kl_partials gets reparam_linear_tiles(B) entries
+bool reparam_linear_ok(int Z, int N, const void* const* ptrs, int nptr);
+int reparam_linear_tiles(int B);
+hipError_t launch_reparam_linear(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
+                                 uint64_t seed, uint64_t offset, const float* W, const float* bias, float* eps_out,
+                                 float* z_out, float* Y, float* kl_partials, int B, int Z, int N, hipStream_t s);
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
                              uint64_t seed, uint64_t offset, float* eps_out, float* z, float* kl_partials,
                              int64_t n, hipStream_t s);
