@@ -32,10 +32,11 @@ if st:
     g = [r for r in rows if "gemm_grouped" in r["Name"]]
     gt = sum(int(r["TotalDurationNs"]) for r in g)
     gc = sum(int(r["Calls"]) for r in g)
+    nst = max(int(r["Calls"]) for r in rows if "transpose_f32" in r["Name"])  # one weight transpose per step
     print(f"\nGEMM kernel (all pair instantiations): {gc} launches, average {gt/gc/1e3:.2f} us per launch, "
-          f"{gt/1e3/ (gc/12):.1f} us per step (12 launches per step); all psvae kernels {tot/1e3/(gc/12):.1f} us per step "
+          f"{gt/1e3/nst:.1f} us per step ({gc/nst:.0f} launches per step); all psvae kernels {tot/1e3/nst:.1f} us per step "
           f"(bench under the tracer: {steps['ms_per_step']*1e3:.1f} us/step wall).\n")
-for tag, title in (("pmc_sq", "SQ / TCC counters (per step, summed over the 12 GEMM launches of the last step)"),
+for tag, title in (("pmc_sq", "SQ / TCC counters (summed over the MFMA-carrying launches of the last step)"),
                    ("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(out + f"/{tag}/**/*counter_collection.csv", recursive=True)
     if not f:
@@ -47,7 +48,13 @@ for tag, title in (("pmc_sq", "SQ / TCC counters (per step, summed over the 12 G
         did = int(r["Dispatch_Id"])
         by[did][r["Counter_Name"]] += float(r["Counter_Value"])
         names[did] = r["Kernel_Name"]
-    gemm = [i for i in sorted(by) if "gemm_grouped" in names[i]][-12:]
+    ids = sorted(by)
+    last_t = max(i for i in ids if "transpose_f32" in names[i])  # the last step starts at its weight transpose
+    gemm = [i for i in ids if i > last_t and ("gemm_grouped" in names[i] or "reparam_linear" in names[i])]
+    if len([i for i in ids if i > last_t]) < 10:  # the run ended inside that step: take the one before
+        prev_t = max(i for i in ids if "transpose_f32" in names[i] and i < last_t)
+        gemm = [i for i in ids if prev_t < i < last_t and ("gemm_grouped" in names[i] or "reparam_linear" in names[i])]
+    print(f"({len(gemm)} launches)\n")
     agg = defaultdict(float)
     for i in gemm:
         for k, v in by[i].items():
