@@ -495,7 +495,17 @@ static double wg_cycles(const GemmDesc& d, const Cfg& c) {
     double per_chunk = 4.0 * c.TM * c.TN * 32.0 / c.eff;
     if (d.kind == GK_NT) per_chunk *= 1.25;  // both operands k-contiguous: half-used 128-B lines per load
     if (d.kind == GK_TN) per_chunk *= 0.9;   // both operands k-major: whole lines, fewest address-unit cycles
-    return full * per_chunk + rem * per_chunk * 1.6 + 2200.0 + 150.0 * c.KS;
+    double cyc = full * per_chunk + rem * per_chunk * 1.6;
+    // operand delivery: a workgroup pulls (BM + BN) * K * 4 bytes through its CU's L1 at ~11 B/clk when every CU is
+    // busy (tools/microbench/load_rate.hip); wide tiles are MFMA-bound, 64x64 and smaller are bound by this
+    static const double bpc = env_int("PSVAE_COST_BPC", 11);
+    if (bpc > 0) {
+        const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
+        const double bytes = (double)(BM + BN) * (16.0 * chunks) * 4.0;
+        const double feed = bytes / bpc;
+        cyc = cyc > feed ? cyc : feed;
+    }
+    return cyc + 2200.0 + 150.0 * c.KS;
 }
 static long wg_count(const GemmDesc& d, const Cfg& c) {
     const int BM = c.WM * 16 * c.TM, BN = c.WN * 16 * c.TN;
@@ -537,8 +547,9 @@ int pick_tile(const GemmBatch& b) {  // config of the first problem (test hook s
 }
 
 static const int kTnCands[] = {1, 2, 8};           // wgrad: small tiles, k split 4 (a tuned plan may also pick 6)
-constexpr int NTN = 3, NOTHER = 5;
-static const int kOtherCands[] = {1, 2, 4, 6, 8};  // forward / dgrad
+constexpr int NTN = 3, NOTHER = 5, NOTHER_NO_TN = 7;
+static const int kOtherCands[] = {1, 2, 4, 6, 8, 7, 9};  // forward / dgrad; 7 and 9 (128-wide tiles) only in launches
+                                                        // without weight-gradient problems (no mixed pair compiled)
 
 // cfg == 0: choose one config for the TN problems and one for the others; else force `cfg` everywhere
 void finalize_batch(GemmBatch& b, int cfg) {
@@ -557,7 +568,7 @@ void finalize_batch(GemmBatch& b, int cfg) {
         for (int i = 0; i < b.n; ++i) (b.d[i].kind == GK_TN ? has_tn : has_other) = true;
         double best = 1e30;
         for (int a = 0; a < (has_tn ? NTN : 1); ++a)
-            for (int o = 0; o < (has_other ? NOTHER : 1); ++o) {
+            for (int o = 0; o < (has_other ? (has_tn ? NOTHER : NOTHER_NO_TN) : 1); ++o) {
                 const int ct = has_tn ? kTnCands[a] : kOtherCands[o], co = has_other ? kOtherCands[o] : ct;
                 const double e = launch_cost(b, ct, co);
                 if (e < best) { best = e; pick_tn = ct; pick_other = co; }

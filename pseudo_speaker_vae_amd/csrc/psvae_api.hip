@@ -595,12 +595,12 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     StepPlan best{};
     float t_best = 0.f;
     rc = measure(best, &t_best);
-    static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8};
+    static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8, 7, 9};  // 7, 9: launches without wgrads only
     for (int pass = 0; pass < 2 && rc == 0; ++pass) {
         for (int site = 0; site < NSITE && rc == 0; ++site) {
             const bool has_tn = site >= 6, has_other = site != 11;
             for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
-                for (int o = 0; o < (has_other ? 5 : 1) && rc == 0; ++o)
+                for (int o = 0; o < (has_other ? (has_tn ? 5 : 7) : 1) && rc == 0; ++o)
                     for (int ks = 1; ks <= (has_tn ? WGRAD_SMAX : 1) && rc == 0; ks *= 2)
                         for (int capv = 1; capv <= 2 && rc == 0; ++capv)
                             for (int rm = 1; rm <= 2 && rc == 0; ++rm) {
