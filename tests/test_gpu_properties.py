@@ -1,0 +1,111 @@
+"""Size-independent properties of the HIP hot path at BASELINE.json's full sizes (the oracle is too slow to be
+the checker there): gradient linearity in the loss scale, the data-parallel identity (mean of shard gradients ==
+full-batch gradient), loss identities, Philox-stream continuity across batch splits, decode row
+independence at 1 M rows."""
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import psvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _step(ops, params, x, eps, beta=1.0, go=None):
+    B, D = x.shape
+    Z = eps.shape[1]
+    ws = ops.Workspace(B, D, Z, DEV)
+    grads = [torch.full_like(t, float("nan")) for t in params]
+    loss3 = torch.full((3,), float("nan"), device=DEV)
+    outs = ws.new_outputs()
+    ops.train_step(ws, x, params, grads, outs, loss3, beta=beta, eps=eps,
+                   grad_loss=None if go is None else torch.tensor([go], device=DEV))
+    torch.cuda.synchronize()
+    return loss3.clone(), grads, outs, ws
+
+
+@pytest.mark.parametrize("D,Z,B", [(256, 64, 1024), (512, 128, 1024), (256, 64, 4096)])
+def test_gradients_are_linear_in_the_loss_scale(D, Z, B):
+    from pseudo_speaker_vae_amd import ops
+    p = O.init_params(D, Z, 2)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    g = torch.Generator().manual_seed(B + D)
+    x, eps = torch.randn(B, D, generator=g).to(DEV), torch.randn(B, Z, generator=g).to(DEV)
+    l1, g1, _, _ = _step(ops, params, x, eps, 0.7, go=1.0)
+    l2, g2, _, _ = _step(ops, params, x, eps, 0.7, go=-2.5)
+    assert torch.equal(l1, l2)  # the loss itself does not depend on the upstream scale
+    assert abs(float(l1[0]) - (float(l1[1]) + 0.7 * float(l1[2]))) <= 1e-6 * max(1.0, abs(float(l1[0])))
+    assert float(l1[2]) >= 0.0  # KL(q || N(0, I)) >= 0
+    for k, a, b in zip(O.PARAM_KEYS, g1, g2):
+        assert_close(b.cpu(), (-2.5 * a).cpu(), 2e-6, "linearity " + k)
+
+
+@pytest.mark.parametrize("D,Z,B", [(256, 64, 1024), (512, 128, 2048)])
+def test_mean_of_shard_gradients_is_the_full_batch_gradient(D, Z, B):
+    """what the DDP all-reduce relies on (training.py:78): with the batch cut in W shards, the mean over shards of
+    the per-shard gradients (each normalised by its own B/W) equals the full-batch gradient"""
+    from pseudo_speaker_vae_amd import ops
+    p = O.init_params(D, Z, 4)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    g = torch.Generator().manual_seed(B)
+    x, eps = torch.randn(B, D, generator=g).to(DEV), torch.randn(B, Z, generator=g).to(DEV)
+    lf, gf, _, _ = _step(ops, params, x, eps)
+    W = 4
+    acc = [torch.zeros_like(t) for t in params]
+    ls = torch.zeros(3, device=DEV)
+    for r in range(W):
+        sl = slice(r * B // W, (r + 1) * B // W)
+        l, gs, _, _ = _step(ops, params, x[sl].contiguous(), eps[sl].contiguous())
+        ls += l / W
+        for a, t in zip(acc, gs):
+            a += t / W
+    assert_close(ls.cpu(), lf.cpu(), 2e-6, "loss")
+    for k, a, b in zip(O.PARAM_KEYS, acc, gf):
+        assert_close(a.cpu(), b.cpu(), 2e-5, "shard mean " + k)
+
+
+def test_philox_stream_is_continuous_across_batch_splits():
+    """the device-resident Philox state advances by exactly the blocks a batch consumed: two half batches draw
+    the same epsilon as one full batch that starts at the same state"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z, B = 256, 64, 1024
+    p = O.init_params(D, Z, 0)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    x = torch.randn(B, D).to(DEV)
+
+    def run(xs, state):
+        ws = ops.Workspace(xs.shape[0], D, Z, DEV)
+        grads = [torch.empty_like(t) for t in params]
+        loss3 = torch.empty(3, device=DEV)
+        ops.train_step(ws, xs, params, grads, ws.new_outputs(), loss3, rng_state=state)
+        torch.cuda.synchronize()
+        return ws.acts["eps"].clone()
+
+    s1 = torch.tensor([77, 1000], dtype=torch.int64, device=DEV)
+    full = run(x, s1)
+    assert int(s1[1]) == 1000 + B * Z // 4
+    s2 = torch.tensor([77, 1000], dtype=torch.int64, device=DEV)
+    a = run(x[: B // 2].contiguous(), s2)
+    b = run(x[B // 2:].contiguous(), s2)
+    assert torch.equal(torch.cat([a, b]), full)
+    ref = O.philox_normal(B * Z, 77, 1000).reshape(B, Z)
+    assert_close(full.cpu(), ref, 1e-5, "eps vs oracle Philox")
+
+
+def test_decode_rows_are_independent_at_one_million_rows():
+    """cfg5: every output row depends on its own latent row only -- decoding 1,000,000 rows in one call equals
+    decoding any slice of them alone (chunk boundaries at 65,536 rows are invisible)"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z, N = 256, 64, 1_000_000
+    p = O.init_params(D, Z, 9)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(N * Z, 5, 0, DEV).reshape(N, Z)
+    full = ops.decode(z, dec, D)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all()
+    for lo, hi in ((0, 100), (65_530, 65_545), (499_999, 500_131), (N - 37, N)):
+        part = ops.decode(z[lo:hi].contiguous(), dec, D)
+        assert_close(part.cpu(), full[lo:hi].cpu(), 2e-6, f"rows {lo}:{hi}")
+    ref = O.decode(p, z[:64].cpu())
+    assert_close(full[:64].cpu(), ref, 1e-4, "first rows vs oracle")
