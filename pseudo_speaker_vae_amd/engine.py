@@ -60,7 +60,8 @@ class TrainEngine:
     def __init__(self, input_dim: int, latent_dim: int, batch: int, device="cuda:0", seed: int = 0,
                  beta: float = 1.0, normalize_decoder: bool = False, use_cos_loss: bool = False,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 process_group=None, state_dict=None, dtype: str = "f32", conditional: bool = False):
+                 process_group=None, state_dict=None, dtype: str = "f32", conditional: bool = False,
+                 shard: Optional[tuple] = None):
         """dtype "bf16" = BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulate / master weights /
         gradients); conditional = one-hot gender+age gather tables."""
         if dtype not in ("f32", "bf16"):
@@ -76,9 +77,15 @@ class TrainEngine:
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, eps, weight_decay
         self.pg = process_group
         self.world = 1
+        self.rank = 0
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+            self.rank = dist.get_rank(process_group)
+        if shard is not None:  # (rank, world) of the epsilon stream without a process group (tests)
+            self.rank, self._eps_world = int(shard[0]), int(shard[1])
+        else:
+            self._eps_world = self.world
 
         # default nn.Linear init in the reference's creation order under `seed` (CPU generator), so
         # every rank starts from identical parameters without a broadcast (Coll-4 of SURVEY.md 2.2)
@@ -120,8 +127,13 @@ class TrainEngine:
             self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
             self.outs = self.ws.new_outputs()
         self.step_count = 0
-        # device-resident Philox state {seed, offset}: advanced by the forward itself (graph-safe)
-        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+        # device-resident Philox state {seed, offset}: advanced by the forward itself (graph-safe).  Data-parallel
+        # ranks share the seed and interleave their counter ranges by GLOBAL row index: rank r starts
+        # r * nblk blocks in, and after each step every rank skips the other ranks' blocks -- W ranks of B/W rows
+        # draw exactly the epsilon one rank with B rows would.
+        self._nblk = (batch * latent_dim + 3) // 4
+        self.rng_state = torch.tensor([seed, self.rank * self._nblk], dtype=torch.int64, device=self.device)
+        self._rng_skip = (self._eps_world - 1) * self._nblk
         self._graph = None
         self.static_x = None
 
@@ -130,6 +142,16 @@ class TrainEngine:
         return {k: p.detach().clone() for k, p in zip(self.keys, self.params)}
 
     def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):
+        self._forward_backward(x, eps, _local_only)
+        if eps is None:
+            self._skip_rng()
+
+    def _skip_rng(self):
+        """jump over the other ranks' Philox blocks (a torch op: captured steps carry it)"""
+        if self._rng_skip:
+            self.rng_state[1:2].add_(self._rng_skip)
+
+    def _forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):
         """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
         if self.dtype == "bf16":
@@ -237,6 +259,7 @@ class TrainEngine:
                 self.averager.reduce_bucket(1)
                 ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
                                phases=_ffi.PHASE_ENCODER, **kw)
+                self._skip_rng()
                 self.averager.reduce_bucket(0)
             else:
                 self.forward_backward(self.static_x, _local_only=True)
@@ -282,6 +305,7 @@ class TrainEngine:
         with torch.cuda.graph(self._gb, pool=self._ga.pool()):
             ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,
                            phases=_ffi.PHASE_ENCODER, **kw)
+            self._skip_rng()
 
     def replay_ddp(self):
         self._ga.replay()

@@ -109,3 +109,33 @@ def test_decode_rows_are_independent_at_one_million_rows():
         assert_close(part.cpu(), full[lo:hi].cpu(), 2e-6, f"rows {lo}:{hi}")
     ref = O.decode(p, z[:64].cpu())
     assert_close(full[:64].cpu(), ref, 1e-4, "first rows vs oracle")
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_data_parallel_epsilon_stream_is_world_size_invariant(graph):
+    """ranks share the seed and interleave their Philox counters by global row index, so W ranks of
+    B/W rows draw, step after step, exactly the epsilon one rank with B rows draws (eager and captured)"""
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    D, Z, B, W = 256, 64, 1024, 4
+    x = torch.randn(B, D, device=DEV)
+    full = TrainEngine(D, Z, B, device=DEV, seed=11)
+    shards = [TrainEngine(D, Z, B // W, device=DEV, seed=11, shard=(r, W)) for r in range(W)]
+    xs = [x[r * B // W:(r + 1) * B // W].contiguous() for r in range(W)]
+    if graph:
+        full.capture(x)
+        for e, xr in zip(shards, xs):
+            e.capture(xr)
+    seen = []
+    for step in range(3):
+        if graph:
+            full.replay()
+            [e.replay() for e in shards]
+        else:
+            full.forward_backward(x)
+            [e.forward_backward(xr) for e, xr in zip(shards, xs)]
+        torch.cuda.synchronize()
+        eps_full = full.ws.acts["eps"].clone()
+        eps_sh = torch.cat([e.ws.acts["eps"] for e in shards])
+        assert torch.equal(eps_sh, eps_full), f"step {step}"
+        seen.append(eps_full)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])  # fresh noise every step
