@@ -598,6 +598,8 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8, 7, 9};  // 7, 9: launches without wgrads only
     for (int pass = 0; pass < 2 && rc == 0; ++pass) {
         for (int site = 0; site < NSITE && rc == 0; ++site) {
+            // decoder layer 0 normally runs inside the bottleneck kernel: its GEMM site has nothing to tune
+            if (site == 3 && getenv("PSVAE_NO_BOTTLENECK") == nullptr && (dims->Z & 15) == 0 && dims->Z <= 128) continue;
             const bool has_tn = site >= 6, has_other = site != 11;
             for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
                 for (int o = 0; o < (has_other ? (has_tn ? 5 : 7) : 1) && rc == 0; ++o)
