@@ -7,6 +7,7 @@ torch.autograd.Functions; inputs must live on the GPU -- there is no CPU fallbac
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -66,6 +67,9 @@ def _alloc_like_flat(tensors):
     return out
 
 
+_FUSED_AUTOGRAD = os.environ.get("PSVAE_AUTOGRAD_FUSED", "1") != "0"  # tuning switch
+
+
 class _Ctx:
     """what backward needs, shared by both Functions"""
     __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors")
@@ -93,6 +97,30 @@ def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_te
     cond = _make_cond(cond_tensors, None)
     ops.vae_forward(ws, x, params, eps, seed, offset, flags, cond=cond, outs=(xh, mu, lv))
     return c, x, xh, mu, lv
+
+
+def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers):
+    """psvae_train_step_f32 on fresh buffers: returns ctx, outputs, the loss triple and the 18 gradients (d total = 1)"""
+    if not x.is_cuda:
+        raise _ffi.PsvaeError("VAEModel runs on the GPU only (HIP kernels); move the module and its input to cuda")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise _ffi.PsvaeError(f"expected float32 input, got {x.dtype}")
+    B, D = x.shape
+    Z = params[4].shape[0]
+    if params[0].shape[1] != D:
+        raise _ffi.PsvaeError(f"input has {D} features, the model expects {params[0].shape[1]}")
+    c = _Ctx()
+    c.B, c.D, c.Z, c.flags = B, D, Z, 0
+    c.acts, xh, mu, lv = _alloc_acts(B, D, Z, x.device, False)
+    c.acts_c = _ffi.make_acts(c.acts)
+    c.scratch = buffers.scratch(B, D, Z, x.device)
+    c.dims = _ffi.Dims(B, D, Z)
+    c.cond_tensors = None
+    grads = _alloc_like_flat(params)
+    loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
+    ops.train_step(_WsView(c), x, params, grads, (xh, mu, lv), loss3, beta=beta, eps=eps, seed=seed, offset=offset)
+    return c, x, xh, mu, lv, loss3, grads
 
 
 def _make_cond(cond_tensors, gtabs):
@@ -150,9 +178,16 @@ class ELBOStepFunction(torch.autograd.Function):
         vae_params = params[:_ffi.NPARAM]
         if ncond:
             cond_tensors = (params[_ffi.NPARAM:], cond_tensors[1], cond_tensors[2])
-        c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers, cond_tensors)
-        loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
-        ops.elbo(_WsView(c), x, xh, mu, lv, beta, flags, loss3)
+        ctx.fused_grads = None
+        if flags == 0 and not ncond and any(ctx.needs_input_grad[3:]) and _FUSED_AUTOGRAD:
+            # default loss, parameters want gradients: run the fused 13-launch train step now (forward + ELBO +
+            # backward with d(total) = 1) and hand the gradients out, scaled, when backward() is called
+            c, x, xh, mu, lv, loss3, grads = _run_fused_step(x.detach(), eps, seed, offset, beta, vae_params, buffers)
+            ctx.fused_grads = grads
+        else:
+            c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers, cond_tensors)
+            loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
+            ops.elbo(_WsView(c), x, xh, mu, lv, beta, flags, loss3)
         ctx.c, ctx.params, ctx.x, ctx.beta = c, params, x, beta
         ctx.save_for_backward(xh, mu, lv)
         total, recon, kl = loss3[0], loss3[1], loss3[2]
@@ -161,6 +196,11 @@ class ELBOStepFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, *_):
+        if ctx.fused_grads is not None:  # gradients are linear in d(total): scale the precomputed ones on the device
+            grads = ctx.fused_grads
+            ctx.fused_grads = None
+            grads[0]._base.mul_(g_total.float()) if grads[0]._base is not None else [g.mul_(g_total.float()) for g in grads]
+            return (None, None, None, *grads)
         xh, mu, lv = ctx.saved_tensors
         c = ctx.c
         grads = _alloc_like_flat(ctx.params)

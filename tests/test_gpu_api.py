@@ -307,3 +307,31 @@ def test_model_tune_then_training_step_still_matches_oracle():
     assert_close(xh.detach().cpu(), acts["x_hat"], REL_TOL, "x_hat")
     for k, t in zip(O.PARAM_KEYS, m.ordered_params()):
         assert_close(t.grad.cpu(), ograds[k], 5e-4, "grad " + k)  # no mask alignment here: allow a ReLU-kink flip
+
+
+def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
+    """elbo_step with the default loss runs the fused train step inside forward() and hands out its gradients in
+    backward(), scaled by d(total) on the device: check against the oracle with an upstream factor, twice (fresh
+    buffers every call), and that a no-grad call leaves no gradients behind."""
+    import torch
+    from oracle import psvae_oracle as O
+    from pseudo_speaker_vae_amd.model import VAEModel
+    from helpers import assert_close, REL_TOL
+    D, Z, B = 256, 64, 200
+    m = VAEModel(D, Z).to("cuda:0")
+    p = {k: v.detach().cpu() for k, v in zip(O.PARAM_KEYS, m.ordered_params())}
+    for trial, scale in enumerate((1.0, -2.5)):
+        torch.manual_seed(trial)
+        x, eps = torch.randn(B, D), torch.randn(B, Z)
+        m.zero_grad(set_to_none=True)
+        total, recon, kl, xh, mu, lv = m.elbo_step(x.cuda(), beta=1.3, eps=eps.cuda())
+        (total * scale).backward()
+        losses, ograds, acts, _ = O.train_step(p, x, eps, 1.3, go=scale)
+        assert abs(float(total) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
+        assert_close(mu.cpu(), acts["mu"], REL_TOL, "mu")
+        for k, t in zip(O.PARAM_KEYS, m.ordered_params()):
+            assert_close(t.grad.cpu(), ograds[k], 5e-4, f"scale {scale} grad {k}")
+    m.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        total, *_ = m.elbo_step(torch.randn(B, D, device="cuda:0"))
+    assert torch.isfinite(total) and all(t.grad is None for t in m.ordered_params())
