@@ -22,6 +22,8 @@
 //   * bias gradients (column sums of dY) come from the A fragments already in registers.
 #include <string.h>
 
+#include <mutex>
+
 #include "psvae_common.h"
 
 namespace psvae {
@@ -555,24 +557,44 @@ static const int kOtherCands[] = {1, 2, 4, 6, 8, 7, 9};  // forward / dgrad; 7 a
 void finalize_batch(GemmBatch& b, int cfg) {
     if (g_forced < 0) g_forced = env_int("PSVAE_TILE", 0);
     if (cfg == 0 && g_forced > 0 && g_forced <= NCFG) cfg = g_forced;
-    double flops[MAX_GROUP], tot = 0;
-    for (int i = 0; i < b.n; ++i) {
-        flops[i] = (double)b.d[i].M * b.d[i].N * b.d[i].K;
-        tot += flops[i];
-    }
     int pick_tn = cfg, pick_other = cfg;
     static const int force_tn = env_int("PSVAE_CFG_TN", 0), force_other = env_int("PSVAE_CFG_OTHER", 0);  // tuning
     if (cfg == 0) {
         // joint choice: the pair (TN config, config of the others) with the smallest modelled makespan
         bool has_tn = false, has_other = false;
         for (int i = 0; i < b.n; ++i) (b.d[i].kind == GK_TN ? has_tn : has_other) = true;
-        double best = 1e30;
-        for (int a = 0; a < (has_tn ? NTN : 1); ++a)
-            for (int o = 0; o < (has_other ? (has_tn ? NOTHER : NOTHER_NO_TN) : 1); ++o) {
-                const int ct = has_tn ? kTnCands[a] : kOtherCands[o], co = has_other ? kOtherCands[o] : ct;
-                const double e = launch_cost(b, ct, co);
-                if (e < best) { best = e; pick_tn = ct; pick_other = co; }
-            }
+        // (memoised per problem signature: the model costs ~10 us of host time, which an eager launch sequence --
+        // the autograd path -- would pay 13 times per step)
+        struct Memo { int key[MAX_GROUP][5]; int n, tn, other; };
+        static Memo memo[64];
+        static int memo_n = 0;
+        static std::mutex memo_mu;
+        int key[MAX_GROUP][5] = {};
+        for (int i = 0; i < b.n; ++i) {
+            key[i][0] = b.d[i].M; key[i][1] = b.d[i].N; key[i][2] = b.d[i].K; key[i][3] = b.d[i].kind;
+            key[i][4] = b.d[i].ksplit > 1 ? b.d[i].ksplit : 1;
+        }
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(memo_mu);
+            for (int m = 0; m < memo_n && !hit; ++m)
+                if (memo[m].n == b.n && memcmp(memo[m].key, key, sizeof(key)) == 0) {
+                    pick_tn = memo[m].tn; pick_other = memo[m].other; hit = true;
+                }
+        }
+        if (!hit) {
+            double best = 1e30;
+            for (int a = 0; a < (has_tn ? NTN : 1); ++a)
+                for (int o = 0; o < (has_other ? (has_tn ? NOTHER : NOTHER_NO_TN) : 1); ++o) {
+                    const int ct = has_tn ? kTnCands[a] : kOtherCands[o], co = has_other ? kOtherCands[o] : ct;
+                    const double e = launch_cost(b, ct, co);
+                    if (e < best) { best = e; pick_tn = ct; pick_other = co; }
+                }
+            std::lock_guard<std::mutex> lk(memo_mu);
+            Memo& m = memo[memo_n < 64 ? memo_n++ : (memo_n = 1, 0)];  // full: start over
+            memcpy(m.key, key, sizeof(key));
+            m.n = b.n; m.tn = pick_tn; m.other = pick_other;
+        }
         if (force_tn > 0 && force_tn <= NCFG) pick_tn = force_tn;
         if (force_other > 0 && force_other <= NCFG) pick_other = force_other;
         if (b.hint_tn > 0 && b.hint_tn <= NCFG) pick_tn = b.hint_tn;  // a tuned plan wins
