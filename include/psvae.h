@@ -6,8 +6,9 @@
  *
  * Conventions
  *   - every buffer is caller-owned device memory (fp32, row-major, contiguous unless stated);
- *     the library allocates nothing persistent and keeps no pointer after a call returns
- *     (exception: the explicit psvae_plan_* handle, which owns a captured hipGraph);
+ *     the library allocates nothing persistent and keeps no pointer after a call returns; its only process
+ *     state is the table of tuned launch plans per (B, D, Z) (psvae_tune_train_step_f32 / psvae_set_plan:
+ *     small host structs, speed only) and the memo of launch-configuration choices;
  *   - all work is enqueued on `stream`; no call synchronises the device or the host;
  *   - return 0 on success, <0 for an argument error detected before any launch, >0 = hipError_t;
  *     psvae_strerror() maps both; no C++ exception crosses the boundary;
@@ -43,7 +44,7 @@ extern "C" {
 #define PSVAE_ERR_SHAPE -2  /* non-positive or unsupported dimension */
 #define PSVAE_ERR_ALIGN -3  /* a pointer is not 16-byte aligned */
 #define PSVAE_ERR_ARG -4    /* bad enum / flag / phase value */
-#define PSVAE_ERR_STATE -5  /* plan misuse */
+#define PSVAE_ERR_STATE -5  /* call not valid in this state (e.g. tuning while the stream is capturing) */
 
 typedef struct psvae_dims {
     int64_t B; /* batch rows */
@@ -131,7 +132,8 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
 
 /* One whole training pass = psvae_forward_f32 + psvae_elbo_f32 + psvae_backward_f32(elbo=1) for the
  * default loss (MSE/10 + beta*KL, no decoder normalisation), as ONE launch sequence with the elementwise
- * work folded into GEMM epilogues (14 launches instead of 19).  What a Lightning step does between
+ * work folded into GEMM epilogues and one dedicated reparameterise + decoder.0 kernel (13 launches instead of
+ * 19; one more when a tuned plan splits a weight gradient over workgroups).  What a Lightning step does between
  * lightning.py:67 and the end of loss.backward().  phases: PSVAE_PHASE_DECODER = forward + decoder
  * backward (decoder gradients and loss3 complete), PSVAE_PHASE_ENCODER = encoder backward. */
 int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
