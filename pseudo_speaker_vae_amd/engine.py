@@ -189,14 +189,15 @@ class TrainEngine:
 
     def tune(self, x: torch.Tensor, iters: int = 10, plan: Optional[str] = None) -> str:
         """Autotune the fused step's launch plan for this batch shape (fp32, default loss, unconditional only;
-        a no-op otherwise).  Takes a few seconds once; later steps -- eager or captured -- use the plan.  Gradients,
+        a no-op otherwise).  Takes a few seconds once (or no time with a plan cache file, $PSVAE_PLAN_CACHE); later
+        steps -- eager or captured -- use the plan.  Gradients,
         outputs and the loss buffer are overwritten.  Returns the plan's text form."""
         if self.dtype != "f32" or self.flags != 0 or self.conditional:
             return "untuned"
         if plan is not None:  # reuse a plan tuned earlier (text form) instead of measuring
             ops.set_plan(self.ws, plan)
             return ops.describe_plan(self.ws)
-        return ops.tune_train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters)
+        return ops.tune_or_load_plan(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters)
 
     def set_labels(self, gender: torch.Tensor, age: torch.Tensor):
         """conditional engines: integer labels in {-1,0,1,2} for the current batch (labels.py maps)"""

@@ -146,6 +146,34 @@ def tune_train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Seq
     return describe_plan(ws)
 
 
+def tune_or_load_plan(ws: Workspace, x, params, grads, outs, loss3, iters: int = 10, cache_path: Optional[str] = None) -> str:
+    """tune_train_step with a small JSON cache (default: $PSVAE_PLAN_CACHE, none if unset) keyed by GPU name and
+    (B, D, Z): a production job pays the few seconds of tuning once per shape and machine type."""
+    import json, os
+    cache_path = cache_path or os.environ.get("PSVAE_PLAN_CACHE")
+    key = f"{torch.cuda.get_device_name(ws.device)}|{ws.B}x{ws.D}x{ws.Z}"
+    cache = {}
+    if cache_path and os.path.exists(cache_path):
+        try:
+            cache = json.load(open(cache_path))
+        except (OSError, ValueError):
+            cache = {}
+    if key in cache:
+        try:
+            set_plan(ws, cache[key])
+            return describe_plan(ws)
+        except _ffi.PsvaeError:
+            pass  # written by another library version: tune again
+    plan = tune_train_step(ws, x, params, grads, outs, loss3, iters=iters)
+    if cache_path:
+        cache[key] = plan
+        tmp = f"{cache_path}.tmp{os.getpid()}"
+        with open(tmp, "w") as f:
+            json.dump(cache, f, indent=1)
+        os.replace(tmp, cache_path)
+    return plan
+
+
 def describe_plan(ws: Workspace) -> str:
     buf = C.create_string_buffer(1024)
     _ffi.check(_ffi.lib().psvae_describe_plan(C.byref(ws.dims), buf, 1024), "describe_plan")

@@ -299,3 +299,25 @@ def test_autotuned_launch_plan_keeps_results(ops):
         assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
     for k, g in zip(O.PARAM_KEYS, grads):
         assert_close(g.cpu(), ograds[k], REL_TOL, "tuned step vs oracle grad " + k)
+
+
+def test_plan_cache_file_roundtrip(ops, tmp_path):
+    """tune_or_load_plan writes the tuned plan to a JSON cache and a second workspace of the same shape loads it
+    instead of tuning again"""
+    import json
+    D, Z, B = 64, 16, 256
+    p = O.init_params(D, Z, 3)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    x = torch.randn(B, D, device=DEV)
+    cache = str(tmp_path / "plans.json")
+    ws = ops.Workspace(B, D, Z, DEV)
+    grads = [torch.empty_like(t) for t in params]
+    loss3 = torch.empty(3, device=DEV)
+    plan = ops.tune_or_load_plan(ws, x, params, grads, ws.new_outputs(), loss3, iters=2, cache_path=cache)
+    stored = json.load(open(cache))
+    assert list(stored.values()) == [plan] and f"{B}x{D}x{Z}" in list(stored.keys())[0]
+    ops.set_plan(ws, "untuned")
+    assert ops.describe_plan(ws) == "untuned"
+    again = ops.tune_or_load_plan(ws, x, params, grads, ws.new_outputs(), loss3, iters=2, cache_path=cache)
+    assert again == plan == ops.describe_plan(ws)
+    ops.set_plan(ws, "untuned")
