@@ -197,8 +197,9 @@ def main():
             if args.with_adam:
                 eng.optimizer_step()
     elif mode == "graph":
-        in_graph = os.environ.get("PSVAE_DDP_IN_GRAPH", "1")  # 1: one all-reduce inside the graph (default), 2: decoder
-        # bucket overlapped as a parallel graph branch (fork/join costs more than it hides at 1 rank), 0: outside
+        in_graph = os.environ.get("PSVAE_DDP_IN_GRAPH", "0")  # 0 (default): the all-reduce is issued after the graph -- the
+        # plain, everywhere-proven RCCL usage; 1: captured inside the graph (36 us/step less at 1 rank, but multi-rank
+        # capture could not be rehearsed on the 1-GPU box, so it is opt-in); 2: decoder bucket as a parallel graph branch
         if pg is not None and in_graph in ("1", "2"):
             try:
                 eng.capture_with_collective(x, overlap=(in_graph == "2"))
