@@ -396,7 +396,7 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
 // forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs:
 //   reparam also emits KL partial sums; the last decoder GEMM's epilogue also writes the MSE gradient and
 //   MSE partial sums; the reparam-backward kernel also finishes the loss and advances the Philox state.
-// 15 launches (+1 when a weight gradient is split over workgroups) instead of 19.  Only for the default loss
+// 13 launches (+1 when a weight gradient is split over workgroups) instead of 19.  Only for the default loss
 // (MSE/10, no decoder normalisation).
 int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const float* eps_in,
                          uint64_t seed, uint64_t offset, uint64_t* rng_state, const psvae_acts* acts, float* x_hat,

@@ -161,7 +161,7 @@ class TrainEngine:
                 self.averager.reduce_all()
                 self.averager.wait()
             return
-        if self.flags == 0:  # default loss: the fused 14-launch sequence
+        if self.flags == 0:  # default loss: the fused 13-launch sequence
             kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
             if self.averager is None or _local_only:
                 ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
@@ -216,7 +216,7 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def capture(self, x: torch.Tensor):
         """Capture forward + ELBO + backward into one HIP graph (single GPU; launch-bound otherwise:
-        ~20 kernels of a few microseconds each).  The captured step reads its batch from a static
+        13-19 kernels of a few microseconds each).  The captured step reads its batch from a static
         buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which
         the graph itself advances, so every replay draws fresh noise."""
         self.static_x = x.detach().clone()
@@ -287,7 +287,7 @@ class TrainEngine:
         its two halves -- [forward + ELBO + decoder backward] and [encoder backward] -- and replay them around
         the collectives: graph A, all-reduce(decoder bucket) on RCCL's stream, graph B underneath it,
         all-reduce(encoder bucket + loss scalars), wait.  Host cost per step: two graph launches + two
-        collective calls instead of ~14 kernel launches."""
+        collective calls instead of 13 kernel launches."""
         if self.averager is None or self.flags != 0:
             raise _ffi.PsvaeError("capture_ddp needs a process group and the default loss")
         self.static_x = x.detach().clone()
