@@ -195,6 +195,17 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
                        float noise_weight, int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
                        float* history, void* stream);
 
+/* LatentClassifier training step on latent rows (latent_classifier.py:7-70 as used at lightning.py:73-98):
+ * logits = W1 z + b1 (hidden == 0) or W2 relu(W1 z + b1) + b2; loss2 = {mean cross entropy against y, number of rows
+ * whose argmax equals the label}; g_z[B,Z] and the parameter gradients are d(mean CE)/d(.) times grad_scale
+ * (overwritten).  Single-label heads with C <= 8, hidden <= 128, Z in {16, 32, 64, 128}; labels in [0, C).
+ * 3 launches (per-row kernel, loss reduction, one grouped GEMM for the weight gradients). */
+size_t psvae_classifier_scratch_bytes(int64_t B, int64_t hidden, int64_t C);
+int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, const float* z, const int64_t* y,
+                            const float* W1, const float* b1, const float* W2 /* hidden > 0 */,
+                            const float* b2 /* hidden > 0 */, float grad_scale, float* loss2, float* g_z, float* gW1,
+                            float* gb1, float* gW2, float* gb2, void* scratch, void* stream);
+
 /* Batch assembly from a packed embedding table resident in HBM: out[b,:] = table[idx[b],:] (an
  * out-of-range index gives a zero row).  Stands in for the per-sample torch.load of
  * ps_vae/data/cv.py:58-76 / vctk.py:51-67 (one tiny file per embedding). */

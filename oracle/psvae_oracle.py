@@ -401,6 +401,18 @@ def classifier_forward(layers, z):
     return h
 
 
+def classifier_ce(layers, z, y):
+    """mean cross entropy of classifier(z) against labels y (lightning.py:73-79) with its gradients by torch autograd
+    on the CPU: returns loss, number of argmax hits, d loss/d z and [(dW, db), ...]"""
+    zz = z.clone().requires_grad_()
+    ps = [(W.clone().requires_grad_(), b.clone().requires_grad_()) for W, b in layers]
+    logits = classifier_forward(ps, zz)
+    loss = torch.nn.functional.cross_entropy(logits, y.long())
+    loss.backward()
+    hits = int((logits.argmax(1) == y).sum())
+    return loss.detach(), hits, zz.grad, [(W.grad, b.grad) for W, b in ps]
+
+
 def langevin(layers, z0, noises, target: int, step_size: float, noise_weight: float):
     """inference.py:77-101 for a multiclass single-label classifier, closed-form gradient:
     grad = d/dz [log_softmax(logits)[target] - 0.5 |z|^2];  z += 0.5 s^2 grad + s w noise."""

@@ -761,6 +761,41 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
     return 0;
 }
 
+size_t psvae_classifier_scratch_bytes(int64_t B, int64_t hidden, int64_t C) {
+    if (B <= 0 || C <= 0 || hidden < 0) return 0;
+    return 2 * align_up((size_t)B * (hidden > 0 ? hidden : 1) * sizeof(float), 256) +
+           align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)2 * classifier_blocks(B) * sizeof(float), 256);
+}
+
+int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, const float* z, const int64_t* y,
+                            const float* W1, const float* b1, const float* W2, const float* b2, float grad_scale,
+                            float* loss2, float* g_z, float* gW1, float* gb1, float* gW2, float* gb2, void* scratch,
+                            void* stream) {
+    if (!z || !y || !W1 || !b1 || !loss2 || !g_z || !gW1 || !gb1 || !scratch) return PSVAE_ERR_NULL;
+    if (hidden > 0 && (!W2 || !b2 || !gW2 || !gb2)) return PSVAE_ERR_NULL;
+    if (B <= 0 || C <= 0 || C > 8 || hidden < 0 || hidden > 128) return PSVAE_ERR_SHAPE;
+    if (!(Z == 16 || Z == 32 || Z == 64 || Z == 128)) return PSVAE_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(g_z) & 15)) return PSVAE_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = reinterpret_cast<char*>(scratch);
+    const size_t hb = align_up((size_t)B * (hidden > 0 ? hidden : 1) * sizeof(float), 256);
+    float* h = reinterpret_cast<float*>(base);
+    float* dh = reinterpret_cast<float*>(base + hb);
+    float* dl = reinterpret_cast<float*>(base + 2 * hb);
+    float* partials = reinterpret_cast<float*>(base + 2 * hb + align_up((size_t)B * C * sizeof(float), 256));
+    RET_IF(launch_classifier_ce(B, (int)Z, (int)hidden, (int)C, z, y, W1, b1, W2, b2, grad_scale / (float)B, h, dh, dl, g_z,
+                                partials, loss2, s));
+    GemmBatch b{};
+    if (hidden > 0) {  // dW2 = dlogits^T h, dW1 = dh^T z; bias gradients = their column sums
+        add(b, make_desc(GK_TN, (int)C, (int)hidden, (int)B, dl, (int)C, h, (int)hidden, gW2, (int)hidden, EPI_NONE, nullptr, gb2));
+        add(b, make_desc(GK_TN, (int)hidden, (int)Z, (int)B, dh, (int)hidden, z, (int)Z, gW1, (int)Z, EPI_NONE, nullptr, gb1));
+    } else {
+        add(b, make_desc(GK_TN, (int)C, (int)Z, (int)B, dl, (int)C, z, (int)Z, gW1, (int)Z, EPI_NONE, nullptr, gb1));
+    }
+    RET_IF(launch_gemm_batch(b, 0, s));
+    return 0;
+}
+
 int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_t* idx, int64_t B, float* out,
                           void* stream) {
     if (!table || !idx || !out) return PSVAE_ERR_NULL;

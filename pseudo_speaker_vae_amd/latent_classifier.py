@@ -2,11 +2,54 @@
 
 Same constructor arguments, module layout (`layers` ModuleList with activations interleaved,
 `output_layers` ModuleDict) and therefore the same state_dict keys.  It is tiny (64 -> C); SURVEY.md
-section 8f ranks it "next" (N1): it runs on plain torch ops here, the HIP path covers the VAE itself.
+section 8f ranks it "next" (N1).  `forward` is plain torch (any layer count, activation, multi-head); the head the
+reference actually trains with -- single label, one or two Linear layers with ReLU -- also has a fused HIP
+training step, `LatentClassifier.cross_entropy_step` (psvae_classifier_ce_f32: per-row kernel + one grouped GEMM
+for the weight gradients), which `PseudoSpeakerVAE.training_step` uses when it applies.
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
+
+from . import _ffi
+
+
+class _ClassifierCEFunction(torch.autograd.Function):
+    """(mean CE, hits) = CE(classifier(z), y): forward runs the fused step with grad_scale = 1 and keeps the
+    gradients; backward hands them out scaled by the upstream d(loss) on the device."""
+
+    @staticmethod
+    def forward(ctx, z, y, hidden, *params):
+        z = z.detach().float().contiguous()
+        y = y.to(device=z.device, dtype=torch.int64).contiguous()
+        B, Z = z.shape
+        ps = [p.detach().float().contiguous() for p in params]
+        W1, b1 = ps[0], ps[1]
+        W2, b2 = (ps[2], ps[3]) if hidden else (None, None)
+        C = (W2 if hidden else W1).shape[0]
+        lib = _ffi.lib()
+        scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=z.device)
+        loss2 = torch.empty(2, dtype=torch.float32, device=z.device)
+        g_z = torch.empty_like(z)
+        grads = [torch.empty_like(p) for p in ps]
+        _ffi.check(lib.psvae_classifier_ce_f32(
+            B, Z, hidden, C, _ffi.ptr(z), _ffi.ptr(y), _ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(W2), _ffi.ptr(b2), 1.0,
+            _ffi.ptr(loss2), _ffi.ptr(g_z), _ffi.ptr(grads[0]), _ffi.ptr(grads[1]),
+            _ffi.ptr(grads[2]) if hidden else None, _ffi.ptr(grads[3]) if hidden else None, _ffi.ptr(scratch),
+            _ffi.stream_ptr()), "classifier_ce")
+        ctx.g_z, ctx.grads = g_z, grads
+        loss, hits = loss2[0], loss2[1]
+        ctx.mark_non_differentiable(hits)
+        return loss, hits
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_hits):
+        s = g_loss.float()
+        g_z = ctx.g_z.mul_(s) if ctx.needs_input_grad[0] else None
+        grads = [g.mul_(s) for g in ctx.grads]
+        ctx.g_z = ctx.grads = None
+        return (g_z, None, None, *grads)
 
 _ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "leaky_relu": nn.LeakyReLU}
 
@@ -40,6 +83,31 @@ class LatentClassifier(nn.Module):
         else:
             for label, n in heads.items():
                 self.output_layers[label] = nn.Linear(hidden_dim, n)
+
+    def fused_params(self, input_dim=None):
+        """(hidden, [W1, b1(, W2, b2)]) when the fused HIP step covers this head: single label, one or two Linear
+        layers with ReLU between them, hidden <= 128, C <= 8, input dim in {16, 32, 64, 128}; else None"""
+        if not self.single_label_mode:
+            return None
+        mods = list(self.layers)
+        lins = [m for m in mods if isinstance(m, nn.Linear)]
+        acts = [m for m in mods if not isinstance(m, nn.Linear)]
+        if len(lins) not in (1, 2) or any(not isinstance(a, nn.ReLU) for a in acts):
+            return None
+        hidden = lins[0].out_features if len(lins) == 2 else 0
+        if lins[-1].out_features > 8 or hidden > 128 or lins[0].in_features not in (16, 32, 64, 128):
+            return None
+        return hidden, [p for l in lins for p in (l.weight, l.bias)]
+
+    def cross_entropy_step(self, z: torch.Tensor, y: torch.Tensor):
+        """(mean cross entropy, number of correct rows) of this head on latent rows z[B, Z] against labels y[B] in
+        [0, C), as ONE fused autograd node on the GPU (lightning.py:73-98 with F.cross_entropy's default mean)."""
+        fp = self.fused_params()
+        if fp is None or not z.is_cuda:
+            raise _ffi.PsvaeError("cross_entropy_step covers single-label heads with one or two Linear layers and ReLU, "
+                                  "on the GPU; use forward() + F.cross_entropy for the others")
+        hidden, params = fp
+        return _ClassifierCEFunction.apply(z, y, hidden, *params)
 
     def forward(self, x):
         for layer in self.layers:

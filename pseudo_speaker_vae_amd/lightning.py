@@ -144,8 +144,18 @@ class PseudoSpeakerVAE(_Base):
             x_hat, mu, log_sigma = self(x)
             classifier_loss = 0
             if self.classifier is not None:                                # lightning.py:73-98
-                y_hat = self.classifier(mu)
-                if not self.multilabel:
+                fused_head = (not self.multilabel and mu.is_cuda and self.classifier.fused_params() is not None
+                              and not isinstance(y, dict))
+                if fused_head:  # fused HIP step: CE, accuracy and all classifier gradients in 3 launches
+                    classifier_loss, hits = self.classifier.cross_entropy_step(mu, y)
+                    self.log(f"{prefix}_classifier_acc", hits / x.size(0), sync_dist=True)
+                    self.log(f"{prefix}_classifier_loss", classifier_loss, sync_dist=True)
+                    y_hat = None
+                else:
+                    y_hat = self.classifier(mu)
+                if fused_head:
+                    pass
+                elif not self.multilabel:
                     classifier_loss = nn.functional.cross_entropy(y_hat, y)
                     self.log(f"{prefix}_classifier_acc", self.accuracy(y_hat, y), sync_dist=True)
                     self.log(f"{prefix}_classifier_loss", classifier_loss, sync_dist=True)

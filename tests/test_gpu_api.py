@@ -335,3 +335,64 @@ def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
     with torch.no_grad():
         total, *_ = m.elbo_step(torch.randn(B, D, device="cuda:0"))
     assert torch.isfinite(total) and all(t.grad is None for t in m.ordered_params())
+
+
+@pytest.mark.parametrize("Z,hidden,C,B", [(64, 128, 3, 300), (64, 0, 3, 1000), (32, 64, 8, 257), (128, 16, 2, 64), (16, 0, 5, 33)])
+def test_classifier_cross_entropy_step_matches_oracle(Z, hidden, C, B):
+    """psvae_classifier_ce_f32 behind LatentClassifier.cross_entropy_step: loss, hit count, d/dz and every parameter
+    gradient against torch-CPU autograd (oracle.classifier_ce), with an upstream scale applied in backward."""
+    import torch
+    from oracle import psvae_oracle as O
+    from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
+    from helpers import assert_close, REL_TOL
+    torch.manual_seed(Z + hidden + C)
+    clf = LatentClassifier(Z, C, num_layers=2 if hidden else 1, hidden_dim=max(hidden, 1)).to("cuda:0")
+    z = torch.randn(B, Z)
+    y = torch.randint(0, C, (B,))
+    zg = z.cuda().requires_grad_()
+    loss, hits = clf.cross_entropy_step(zg, y.cuda())
+    (loss * 0.37).backward()
+    lins = [m for m in clf.layers if isinstance(m, torch.nn.Linear)]
+    layers = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in lins]
+    oloss, ohits, ogz, ograds = O.classifier_ce(layers, z, y)
+    assert abs(float(loss) - float(oloss)) <= REL_TOL * max(1.0, abs(float(oloss)))
+    assert int(hits) == ohits
+    assert_close(zg.grad.cpu(), 0.37 * ogz, REL_TOL, "d/dz")
+    for l, (gW, gb) in zip(lins, ograds):
+        assert_close(l.weight.grad.cpu(), 0.37 * gW, REL_TOL, "dW")
+        assert_close(l.bias.grad.cpu(), 0.37 * gb, REL_TOL, "db")
+
+
+def test_training_step_classifier_branch_fused_equals_torch_ops():
+    """the training step with a classifier head: the fused cross-entropy node gives the same total loss and the same
+    gradients (VAE and classifier) as the plain torch-op branch"""
+    import torch
+    from ps_vae.lightning import PseudoSpeakerVAE
+    from helpers import assert_close
+    D, Z, B = 128, 32, 200
+    torch.manual_seed(1)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z),
+                           classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=64, activation="relu"),
+                           classifier_loss_weight=0.3).to("cuda:0")
+    x, y = torch.randn(B, D, device="cuda:0"), torch.randint(0, 3, (B,), device="cuda:0")
+    eps = torch.randn(B, Z, device="cuda:0")
+    mod.model._test_eps = eps
+    orig_forward = mod.model.forward
+    mod.model.forward = lambda xx: orig_forward(xx, eps=eps)  # same noise in both runs
+
+    def run(fused):
+        mod.zero_grad(set_to_none=True)
+        if not fused:
+            saved = mod.classifier.fused_params
+            mod.classifier.fused_params = lambda *a, **k: None
+        out = mod.training_step((x, y), 0)
+        out["loss"].backward()
+        if not fused:
+            mod.classifier.fused_params = saved
+        return float(out["loss"]), [p.grad.clone() for p in mod.parameters()]
+
+    lf, gf = run(True)
+    lt, gt = run(False)
+    assert abs(lf - lt) <= 1e-5 * max(1.0, abs(lt))
+    for a, b in zip(gf, gt):
+        assert_close(a.cpu(), b.cpu(), 2e-4, "fused vs torch-op classifier branch")

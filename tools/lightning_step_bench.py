@@ -1,8 +1,14 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+"""Host-bound cost of the Lightning-style step (training_step + loss.backward()), without and with a classifier head;
+PSVAE_AUTOGRAD_FUSED=0 / --torch-classifier select the unfused paths for comparison."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pseudo_speaker_vae_amd.lightning import PseudoSpeakerVAE
-m = PseudoSpeakerVAE(model={"input_dim": 256, "latent_dim": 64}, lr=1e-3).to("cuda:0")
-x = torch.randn(1024, 256, device="cuda:0"); y = torch.zeros(1024, dtype=torch.long, device="cuda:0")
+with_clf = "--classifier" in sys.argv
+kw = dict(classifier=dict(input_dim=64, num_classes=3, num_layers=2, hidden_dim=128, activation="relu")) if with_clf else {}
+m = PseudoSpeakerVAE(model={"input_dim": 256, "latent_dim": 64}, lr=1e-3, **kw).to("cuda:0")
+if "--torch-classifier" in sys.argv:
+    m.classifier.fused_params = lambda *a, **k: None
+x = torch.randn(1024, 256, device="cuda:0"); y = torch.randint(0, 3, (1024,), device="cuda:0")
 opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 def step():
     opt.zero_grad(set_to_none=True)
@@ -11,4 +17,5 @@ def step():
 for _ in range(20): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): step()
-torch.cuda.synchronize(); print("lightning-style training_step + backward: %.1f us/step" % ((time.perf_counter() - t0) / 200 * 1e6))
+torch.cuda.synchronize()
+print("lightning-style training_step + backward%s: %.1f us/step" % (" (classifier head)" if with_clf else "", (time.perf_counter() - t0) / 200 * 1e6))
