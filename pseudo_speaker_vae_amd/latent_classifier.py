@@ -15,29 +15,36 @@ import torch.nn as nn
 from . import _ffi
 
 
+def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
+    """psvae_classifier_ce_f32 on detached tensors: returns loss2 = {mean CE, hits}, g_z and the parameter gradients
+    (all times grad_scale)"""
+    z = z.detach().float().contiguous()
+    y = y.to(device=z.device, dtype=torch.int64).contiguous()
+    B, Z = z.shape
+    ps = [p.detach().float().contiguous() for p in params]
+    W1, b1 = ps[0], ps[1]
+    W2, b2 = (ps[2], ps[3]) if hidden else (None, None)
+    C = (W2 if hidden else W1).shape[0]
+    lib = _ffi.lib()
+    scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=z.device)
+    loss2 = torch.empty(2, dtype=torch.float32, device=z.device)
+    g_z = torch.empty_like(z)
+    grads = [torch.empty_like(p) for p in ps]
+    _ffi.check(lib.psvae_classifier_ce_f32(
+        B, Z, hidden, C, _ffi.ptr(z), _ffi.ptr(y), _ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(W2), _ffi.ptr(b2),
+        float(grad_scale), _ffi.ptr(loss2), _ffi.ptr(g_z), _ffi.ptr(grads[0]), _ffi.ptr(grads[1]),
+        _ffi.ptr(grads[2]) if hidden else None, _ffi.ptr(grads[3]) if hidden else None, _ffi.ptr(scratch),
+        _ffi.stream_ptr()), "classifier_ce")
+    return loss2, g_z, grads
+
+
 class _ClassifierCEFunction(torch.autograd.Function):
     """(mean CE, hits) = CE(classifier(z), y): forward runs the fused step with grad_scale = 1 and keeps the
     gradients; backward hands them out scaled by the upstream d(loss) on the device."""
 
     @staticmethod
     def forward(ctx, z, y, hidden, *params):
-        z = z.detach().float().contiguous()
-        y = y.to(device=z.device, dtype=torch.int64).contiguous()
-        B, Z = z.shape
-        ps = [p.detach().float().contiguous() for p in params]
-        W1, b1 = ps[0], ps[1]
-        W2, b2 = (ps[2], ps[3]) if hidden else (None, None)
-        C = (W2 if hidden else W1).shape[0]
-        lib = _ffi.lib()
-        scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=z.device)
-        loss2 = torch.empty(2, dtype=torch.float32, device=z.device)
-        g_z = torch.empty_like(z)
-        grads = [torch.empty_like(p) for p in ps]
-        _ffi.check(lib.psvae_classifier_ce_f32(
-            B, Z, hidden, C, _ffi.ptr(z), _ffi.ptr(y), _ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(W2), _ffi.ptr(b2), 1.0,
-            _ffi.ptr(loss2), _ffi.ptr(g_z), _ffi.ptr(grads[0]), _ffi.ptr(grads[1]),
-            _ffi.ptr(grads[2]) if hidden else None, _ffi.ptr(grads[3]) if hidden else None, _ffi.ptr(scratch),
-            _ffi.stream_ptr()), "classifier_ce")
+        loss2, g_z, grads = classifier_ce_raw(z, y, hidden, params)
         ctx.g_z, ctx.grads = g_z, grads
         loss, hits = loss2[0], loss2[1]
         ctx.mark_non_differentiable(hits)

@@ -211,6 +211,43 @@ class ELBOStepFunction(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class ELBOClassifierStepFunction(torch.autograd.Function):
+    """total = ELBO(VAE(x), x) + cw * CE(classifier(mu), y) as ONE autograd node, all on the HIP path
+    (lightning.py:67-131 with a single-label classifier head): forward, ELBO, the classifier's cross-entropy step
+    (whose d/dmu becomes the upstream gradient of mu) and the VAE backward run inside forward(); backward() hands the
+    gradients out scaled by d(total).  Returns (total, recon, kl, ce, hits, x_hat, mu, logvar)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, y, meta, *params):
+        from .latent_classifier import classifier_ce_raw
+        seed, offset, flags, buffers, beta, cw, hidden = meta
+        params = [p.detach() for p in params]
+        vae_params, clf_params = params[:_ffi.NPARAM], params[_ffi.NPARAM:]
+        c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers)
+        loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        ops.elbo(_WsView(c), x, xh, mu, lv, beta, flags, loss3)
+        loss2, g_mu, clf_grads = classifier_ce_raw(mu, y, hidden, clf_params, grad_scale=cw)
+        ctx.all_grads = None
+        if any(ctx.needs_input_grad[4:]):
+            grads = _alloc_like_flat(vae_params)
+            ops.vae_backward(_WsView(c), x, vae_params, xh, mu, lv, grads, g_mu=g_mu, elbo_grad=True, beta=beta, flags=flags)
+            ctx.all_grads = list(grads) + clf_grads
+        total = loss3[0] + cw * loss2[0]
+        recon, kl, ce, hits = loss3[1], loss3[2], loss2[0], loss2[1]
+        ctx.mark_non_differentiable(recon, kl, ce, hits, xh, mu, lv)
+        return total, recon, kl, ce, hits, xh, mu, lv
+
+    @staticmethod
+    def backward(ctx, g_total, *_):
+        grads = ctx.all_grads
+        ctx.all_grads = None
+        s = g_total.float()
+        grads[0]._base.mul_(s)  # the 18 VAE gradients are views of one flat buffer
+        for g in grads[_ffi.NPARAM:]:
+            g.mul_(s)
+        return (None, None, None, None, *grads)
+
+
 class DecodeFunction(torch.autograd.Function):
     """x_hat = decoder(z) on the HIP decode path.  The reference only ever detaches the result
     (inference.py:25,105), so the forward is always available; a backward through decode() is not
@@ -291,6 +328,20 @@ class VAEModel(nn.Module):
         x = torch.randn(batch_size, self.input_dim, device=p0.device)
         loss3 = torch.empty(3, device=p0.device)
         return ops.tune_train_step(ws, x, params, grads, ws.new_outputs(), loss3, iters=iters)
+
+    def elbo_classifier_step(self, x: torch.Tensor, y: torch.Tensor, classifier, beta: float = 1.0,
+                             classifier_weight: float = 1.0, use_cos_loss: bool = False,
+                             eps: Optional[torch.Tensor] = None):
+        """fused forward + ELBO + classifier cross entropy on mu (lightning.py:67-131 with a single-label head the
+        fused classifier step covers): returns (total, recon, kl, ce, hits, x_hat, mu, logvar)."""
+        fp = classifier.fused_params()
+        if fp is None:
+            raise _ffi.PsvaeError("elbo_classifier_step needs a head LatentClassifier.fused_params() accepts")
+        hidden, clf_params = fp
+        seed, off = self._next_rng(x.shape[0] * self.latent_dim)
+        flags = self.flags | (_ffi.COS_LOSS if use_cos_loss else 0)
+        meta = (seed, off, flags, self._scratch_cache, float(beta), float(classifier_weight), hidden)
+        return ELBOClassifierStepFunction.apply(x, eps, y, meta, *self.ordered_params(), *clf_params)
 
     def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
                   eps: Optional[torch.Tensor] = None):
