@@ -46,3 +46,19 @@ for _ in range(n): g.replay()
 e1.record(); torch.cuda.synchronize()
 us = 1e3 * e0.elapsed_time(e1) / n
 print(f"stock PyTorch, HIP graph   : {us:7.1f} us/step  = {B / us:.2f} M embeddings/s  (B={B}, D={D}, Z={Z})")
+
+# decode-only (cfg5): 1,000,000 latent rows through the decoder, no grad, 65,536-row chunks like the product path
+if "--decode" in sys.argv:
+    N = 1_000_000
+    zs = torch.randn(N, Z, device=dev)
+    out = torch.empty(N, D, device=dev)
+    def decode_all():
+        with torch.no_grad():
+            for r0 in range(0, N, 65536):
+                out[r0:r0 + 65536] = dec(zs[r0:r0 + 65536])
+    decode_all(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5): decode_all()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"stock PyTorch decode 1M rows: {ms:7.2f} ms = {N / ms / 1e3:.1f} M embeddings/s")
