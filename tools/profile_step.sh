@@ -16,4 +16,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 be
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --mode eager --steps 20 --warmup 5 --no-cpu-baseline --plan "$PLAN" > /dev/null 2> "$OUT/pmc_write.log"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/SUMMARY.md"
 python3 tools/parse_trace.py "$OUT/trace" 100 > "$OUT/timeline.txt"
-cat "$OUT/SUMMARY.md" "$OUT/timeline.txt"
+python3 tools/launch_roofline.py "$OUT/trace" > "$OUT/launch_roofline.md"
+cat "$OUT/SUMMARY.md" "$OUT/timeline.txt" "$OUT/launch_roofline.md"
