@@ -11,6 +11,7 @@ import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
+import torch.distributed
 import torch.nn as nn
 
 from . import _ffi, ops
@@ -300,8 +301,14 @@ class VAEModel(nn.Module):
         """(seed, offset) of this call's epsilon stream: seed follows torch.manual_seed, the offset
         advances by the Philox blocks the call consumes, so successive forwards never reuse noise."""
         seed = torch.initial_seed() & ((1 << 64) - 1)
-        off = self._philox_offset
-        self._philox_offset += (n_elems + 3) // 4
+        nblk = (n_elems + 3) // 4
+        rank, world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # data-parallel ranks are usually seeded alike (Lightning's seed_everything): interleave their counter
+            # ranges by rank so that shards never share noise (rank r takes the r-th block range of each step)
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        off = self._philox_offset + rank * nblk
+        self._philox_offset += world * nblk
         return seed, off
 
     # ---- reference API -------------------------------------------------------------------
