@@ -321,3 +321,36 @@ def test_plan_cache_file_roundtrip(ops, tmp_path):
     again = ops.tune_or_load_plan(ws, x, params, grads, ws.new_outputs(), loss3, iters=2, cache_path=cache)
     assert again == plan == ops.describe_plan(ws)
     ops.set_plan(ws, "untuned")
+
+
+@pytest.mark.parametrize("split", [1, 4])
+def test_fused_train_step_phases_equal_single_call(ops, split):
+    """psvae_train_step_f32 in two calls (PHASE_DECODER then PHASE_ENCODER: what the overlapped data-parallel step
+    does around its first all-reduce) gives bitwise the same outputs, loss and gradients as one PHASE_ALL call --
+    also when weight gradients are split over workgroups (the decoder-only call must finish its own slabs)."""
+    from pseudo_speaker_vae_amd import _ffi
+    D, Z, B = 256, 64, 1024
+    p = O.init_params(D, Z, 8)
+    torch.manual_seed(3)
+    x, eps = torch.randn(B, D).to(DEV), torch.randn(B, Z).to(DEV)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    assert _ffi.lib().psvae_debug_force_wgrad_split(split) == 0
+    try:
+        res = []
+        for phases in ((_ffi.PHASE_ALL,), (_ffi.PHASE_DECODER, _ffi.PHASE_ENCODER)):
+            ws = ops.Workspace(B, D, Z, DEV)
+            grads = [torch.full_like(t, float("nan")) for t in params]
+            outs = ws.new_outputs()
+            loss3 = torch.full((3,), float("nan"), device=DEV)
+            for i, ph in enumerate(phases):
+                ops.train_step(ws, x, params, grads, outs, loss3, beta=0.9, eps=eps, phases=ph)
+                if len(phases) == 2 and i == 0:  # after the decoder phase: loss and decoder gradients are complete
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(loss3).all() and all(torch.isfinite(g).all() for g in grads[12:])
+            torch.cuda.synchronize()
+            res.append((loss3.clone(), [g.clone() for g in grads], [o.clone() for o in outs]))
+    finally:
+        _ffi.lib().psvae_debug_force_wgrad_split(0)
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
