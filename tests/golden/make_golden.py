@@ -157,6 +157,52 @@ def make_step_case(name, D, Z, B, pseed, dseed, beta=1.0, normalize=False, cos=F
     print(f"{name}: total={loss.item():.6f} recon={fx['recon']:.6f} kl={fx['kl']:.6f}")
 
 
+def make_classifier_step_case(name, D, Z, B, num_layers, hidden, cw, beta=1.0):
+    """the reference's training_step WITH a LatentClassifier head (lightning.py:73-98): total loss, logged classifier
+    loss and accuracy, and every gradient (VAE and classifier) after loss.backward()"""
+    torch.manual_seed(5)
+    hp = dict(model=dict(input_dim=D, latent_dim=Z, normalize_decoder=False), kl_loss_weight=beta,
+              classifier=dict(input_dim=Z, num_classes=3, num_layers=num_layers, hidden_dim=hidden, activation="relu"),
+              classifier_loss_weight=cw)
+    mod = PseudoSpeakerVAE(**hp)
+    with torch.no_grad():
+        for q in mod.classifier.parameters():
+            q.mul_(3.0)  # default init gives near-uniform logits
+    op = O.init_params(D, Z, 5)  # the VAE is created first: its parameters are the seed-5 init
+    for k in O.PARAM_KEYS:
+        assert torch.equal(dict(mod.model.named_parameters())[k].detach(), op[k]), k
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, D, generator=g)
+    y = torch.randint(0, 3, (B,), generator=g)
+    torch.manual_seed(2000)
+    out = mod.training_step((x, y), 0)
+    torch.manual_seed(2000)
+    eps = torch.randn(B, Z)
+    out["loss"].backward()
+    fx = dict(D=D, Z=Z, B=B, pseed=5, beta=beta, cw=cw, x=x.numpy(), y=y.numpy(), eps=eps.numpy(),
+              total=np.float64(out["loss"].item()), recon=np.float64(mod._logged["train_recon_loss"]),
+              kl=np.float64(mod._logged["train_kl_loss"]), ce=np.float64(mod._logged["train_classifier_loss"]),
+              acc=np.float64(mod._logged["train_classifier_acc"]))
+    lins = [l for l in mod.classifier.layers if isinstance(l, nn.Linear)]
+    fx["n_cls_layers"] = len(lins)
+    for i, l in enumerate(lins):
+        fx[f"cls_w{i}"] = l.weight.detach().numpy()
+        fx[f"cls_b{i}"] = l.bias.detach().numpy()
+        fx[f"cls_gw{i}"] = l.weight.grad.numpy().copy()
+        fx[f"cls_gb{i}"] = l.bias.grad.numpy().copy()
+    for i, k in enumerate(O.PARAM_KEYS):
+        gr = dict(mod.model.named_parameters())[k].grad
+        fx[f"gck/{k}"] = checksum(gr)
+        if gr.dim() == 1:
+            fx[f"g/{k}"] = gr.numpy().copy()
+        else:
+            idx = sample_idx(gr.numel(), 7 + i)
+            fx[f"gi/{k}"] = idx
+            fx[f"g/{k}"] = gr.reshape(-1)[idx].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"{name}: total={fx['total']:.6f} ce={fx['ce']:.6f} acc={fx['acc']:.4f}")
+
+
 def make_decode_case(name, D, Z, N, pseed, normalize):
     torch.manual_seed(pseed)
     m = VAEModel(D, Z, normalize)
@@ -242,3 +288,5 @@ if __name__ == "__main__":
     make_langevin_case("langevin_d256_z64_n8_t5", 256, 64, 8, 5, 1, 0.05, 1.0, 2)
     make_langevin_case("langevin_d256_z64_n8_t5_lin", 256, 64, 8, 5, 2, 0.1, 0.5, 1)
     make_label_maps("label_maps")
+    make_classifier_step_case("clfstep_d256_z64_b24_h128", 256, 64, 24, 2, 128, 0.3)
+    make_classifier_step_case("clfstep_d256_z64_b19_lin", 256, 64, 19, 1, 128, 1.0, beta=0.5)

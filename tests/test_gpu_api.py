@@ -396,3 +396,44 @@ def test_training_step_classifier_branch_fused_equals_torch_ops():
     assert abs(lf - lt) <= 1e-5 * max(1.0, abs(lt))
     for a, b in zip(gf, gt):
         assert_close(a.cpu(), b.cpu(), 2e-4, "fused vs torch-op classifier branch")
+
+
+@pytest.mark.parametrize("name", ["clfstep_d256_z64_b24_h128", "clfstep_d256_z64_b19_lin"])
+def test_training_step_with_classifier_head_matches_reference_golden(name):
+    """the fused HIP training step with a classifier head (VAEModel.elbo_classifier_step behind training_step) against
+    the fixture generated from the reference's own training_step + backward"""
+    import numpy as np
+    import torch
+    from oracle import psvae_oracle as O
+    from ps_vae.lightning import PseudoSpeakerVAE
+    import os
+    from helpers import GOLDEN, assert_close, check_grads_against_fixture, load, REL_TOL
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    D, Z, B = int(fx["D"]), int(fx["Z"]), int(fx["B"])
+    nl = int(fx["n_cls_layers"])
+    hidden = fx["cls_w0"].shape[0] if nl == 2 else 128
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), kl_loss_weight=float(fx["beta"]),
+                           classifier=dict(input_dim=Z, num_classes=3, num_layers=nl, hidden_dim=hidden, activation="relu"),
+                           classifier_loss_weight=float(fx["cw"]))
+    p = O.init_params(D, Z, int(fx["pseed"]))
+    mod.model.load_state_dict(p)
+    lins = [l for l in mod.classifier.layers if isinstance(l, torch.nn.Linear)]
+    with torch.no_grad():
+        for i, l in enumerate(lins):
+            l.weight.copy_(torch.from_numpy(fx[f"cls_w{i}"]))
+            l.bias.copy_(torch.from_numpy(fx[f"cls_b{i}"]))
+    mod = mod.to("cuda:0")
+    eps = torch.from_numpy(fx["eps"]).cuda()
+    orig = mod.model.elbo_classifier_step
+    mod.model.elbo_classifier_step = lambda *a, **k: orig(*a, eps=eps, **k)
+    out = mod.training_step((torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["y"]).cuda()), 0)
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(fx["total"])) <= REL_TOL * max(1.0, abs(float(fx["total"])))
+    assert abs(float(mod.logged["train_classifier_loss"]) - float(fx["ce"])) <= REL_TOL * max(1.0, float(fx["ce"]))
+    assert abs(float(mod.logged["train_classifier_acc"]) - float(fx["acc"])) < 1e-6
+    grads = {k: t.grad for k, t in zip(O.PARAM_KEYS, mod.model.ordered_params())}
+    check_grads_against_fixture(grads, fx)
+    lins = [l for l in mod.classifier.layers if isinstance(l, torch.nn.Linear)]
+    for i, l in enumerate(lins):
+        assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"cls_gw{i}"]), REL_TOL, f"classifier dW{i}")
+        assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"cls_gb{i}"]), REL_TOL, f"classifier db{i}")

@@ -140,3 +140,21 @@ def test_adam_matches_torch():
         assert abs(o2.param_groups[0]["lr"] - O.cosine_lr(0.01, ep, 10, 1e-4)) < 1e-9
         o2.step()
         s.step()
+
+
+@pytest.mark.parametrize("name", ["clfstep_d256_z64_b24_h128", "clfstep_d256_z64_b19_lin"])
+def test_training_step_with_classifier_head_matches_reference(name):
+    """oracle.train_step_with_classifier against the reference's own training_step + backward with a LatentClassifier
+    head (lightning.py:67-131): losses, accuracy, all 18 VAE gradients and the classifier's"""
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    layers = [(torch.from_numpy(fx[f"cls_w{i}"]), torch.from_numpy(fx[f"cls_b{i}"])) for i in range(int(fx["n_cls_layers"]))]
+    x, y, eps = torch.from_numpy(fx["x"]), torch.from_numpy(fx["y"]), torch.from_numpy(fx["eps"])
+    losses, grads, cgrads = O.train_step_with_classifier(p, layers, x, y, eps, float(fx["beta"]), float(fx["cw"]))
+    for k in ("total", "recon", "kl", "ce"):
+        assert abs(float(losses[k]) - float(fx[k])) <= 2e-5 * max(1.0, abs(float(fx[k]))), k
+    assert abs(losses["hits"] / x.shape[0] - float(fx["acc"])) < 1e-6
+    check_grads_against_fixture(grads, fx, tol=2e-5)
+    for i, (gW, gb) in enumerate(cgrads):
+        assert_close(gW, torch.from_numpy(fx[f"cls_gw{i}"]), 2e-5, f"classifier dW{i}")
+        assert_close(gb, torch.from_numpy(fx[f"cls_gb{i}"]), 2e-5, f"classifier db{i}")
