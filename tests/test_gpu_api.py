@@ -437,3 +437,28 @@ def test_training_step_with_classifier_head_matches_reference_golden(name):
     for i, l in enumerate(lins):
         assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"cls_gw{i}"]), REL_TOL, f"classifier dW{i}")
         assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"cls_gb{i}"]), REL_TOL, f"classifier db{i}")
+
+
+def test_validation_step_runs_without_grad_on_both_fused_paths():
+    """validation_step (lightning.py:133-197) under torch.no_grad: the fused nodes run forward-only, log the val_ keys and
+    leave no gradients; the totals equal the training-step totals for the same noise"""
+    import torch
+    from ps_vae.lightning import PseudoSpeakerVAE
+    D, Z, B = 128, 32, 96
+    x, y = torch.randn(B, D, device="cuda:0"), torch.randint(0, 3, (B,), device="cuda:0")
+    for with_clf in (False, True):
+        kw = dict(classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=64, activation="relu")) if with_clf else {}
+        mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), **kw).to("cuda:0")
+        torch.manual_seed(5)
+        mod.model._philox_offset = 0
+        with torch.no_grad():
+            out = mod.validation_step((x, y), 0)
+        assert torch.isfinite(out["loss"]) and not out["loss"].requires_grad
+        assert {"val_loss", "val_recon_loss", "val_kl_loss"} <= set(mod.logged)
+        if with_clf:
+            assert {"val_classifier_loss", "val_classifier_acc"} <= set(mod.logged)
+        assert all(p.grad is None for p in mod.parameters())
+        torch.manual_seed(5)
+        mod.model._philox_offset = 0
+        tr = mod.training_step((x, y), 0)
+        assert abs(float(tr["loss"]) - float(out["loss"])) <= 1e-6 * max(1.0, abs(float(out["loss"])))
