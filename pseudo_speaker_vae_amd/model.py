@@ -56,6 +56,17 @@ def _alloc_acts(B: int, D: int, Z: int, device, normalize: bool):
     return acts, xh, mu, lv
 
 
+def _alloc_grads(tensors):
+    """one fresh tensor per gradient: autograd's AccumulateGrad takes such a tensor over as `.grad` without a copy
+    (views of a flat buffer are copied, one small launch each)"""
+    return [torch.empty_like(t) for t in tensors]
+
+
+def _scale_grads(grads, s):
+    """grads *= s (a device scalar), one multi-tensor launch"""
+    torch._foreach_mul_(grads, s)
+
+
 def _alloc_like_flat(tensors):
     """gradients for `tensors` carved out of ONE flat buffer (a single all-reduce payload)."""
     sizes = [t.numel() for t in tensors]
@@ -118,7 +129,7 @@ def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers):
     c.scratch = buffers.scratch(B, D, Z, x.device)
     c.dims = _ffi.Dims(B, D, Z)
     c.cond_tensors = None
-    grads = _alloc_like_flat(params)
+    grads = _alloc_grads(params)
     loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
     ops.train_step(_WsView(c), x, params, grads, (xh, mu, lv), loss3, beta=beta, eps=eps, seed=seed, offset=offset)
     return c, x, xh, mu, lv, loss3, grads
@@ -200,7 +211,7 @@ class ELBOStepFunction(torch.autograd.Function):
         if ctx.fused_grads is not None:  # gradients are linear in d(total): scale the precomputed ones on the device
             grads = ctx.fused_grads
             ctx.fused_grads = None
-            grads[0]._base.mul_(g_total.float()) if grads[0]._base is not None else [g.mul_(g_total.float()) for g in grads]
+            _scale_grads(grads, g_total.float())
             return (None, None, None, *grads)
         xh, mu, lv = ctx.saved_tensors
         c = ctx.c
@@ -230,7 +241,7 @@ class ELBOClassifierStepFunction(torch.autograd.Function):
         loss2, g_mu, clf_grads = classifier_ce_raw(mu, y, hidden, clf_params, grad_scale=cw)
         ctx.all_grads = None
         if any(ctx.needs_input_grad[4:]):
-            grads = _alloc_like_flat(vae_params)
+            grads = _alloc_grads(vae_params)
             ops.vae_backward(_WsView(c), x, vae_params, xh, mu, lv, grads, g_mu=g_mu, elbo_grad=True, beta=beta, flags=flags)
             ctx.all_grads = list(grads) + clf_grads
         total = loss3[0] + cw * loss2[0]
@@ -242,10 +253,7 @@ class ELBOClassifierStepFunction(torch.autograd.Function):
     def backward(ctx, g_total, *_):
         grads = ctx.all_grads
         ctx.all_grads = None
-        s = g_total.float()
-        grads[0]._base.mul_(s)  # the 18 VAE gradients are views of one flat buffer
-        for g in grads[_ffi.NPARAM:]:
-            g.mul_(s)
+        _scale_grads(grads, g_total.float())
         return (None, None, None, None, *grads)
 
 
@@ -286,11 +294,17 @@ class VAEModel(nn.Module):
 
     # ---- helpers -------------------------------------------------------------------------
     def ordered_params(self) -> List[torch.Tensor]:
-        """the 18 tensors in C-ABI order (== creation order == state_dict order)"""
+        """the 18 tensors in C-ABI order (== creation order == state_dict order).  Cached: 18 container lookups per
+        step cost ~40 us of host time; `.to()` and load_state_dict keep the Parameter objects, and the first and last
+        entries are re-checked against the live modules on every call."""
+        cached = self.__dict__.get("_ordered_cache")
+        if cached is not None and cached[0] is self.encoder_mu[0].weight and cached[17] is self.decoder[4].bias:
+            return cached
         out = []
         for blk in (self.encoder_mu, self.encoder_sigma, self.decoder):
             for i in (0, 2, 4):
                 out += [blk[i].weight, blk[i].bias]
+        self.__dict__["_ordered_cache"] = out
         return out
 
     @property
