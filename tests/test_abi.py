@@ -72,3 +72,41 @@ def test_launch_plan_text_roundtrip_and_errors(lib):
     assert lib.psvae_set_plan(C.byref(d), b"untuned") == 0
     assert lib.psvae_describe_plan(C.byref(d), buf, 1024) == 0 and buf.value == b"untuned"
     assert lib.psvae_tune_train_step_f32(C.byref(d), None, None, None, None, None, None, None, None, None, 0, None) == -4
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path, lib):
+    """include/psvae.h is a C header (C99, -pedantic clean) and a C program linked against libpsvae_hip.so resolves the
+    host-only entry points (no GPU needed: version, strerror, scratch sizes, plan text API)"""
+    import shutil
+    import subprocess
+    from pseudo_speaker_vae_amd import _ffi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "c_abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "psvae.h"
+int main(void) {
+    psvae_dims d = {1024, 256, 64};
+    char buf[64];
+    if (psvae_version() != PSVAE_ABI_VERSION) return 1;
+    if (strcmp(psvae_strerror(PSVAE_OK), "ok") != 0) return 2;
+    if (psvae_scratch_bytes(&d) == 0 || psvae_decode_scratch_bytes(10) == 0) return 3;
+    if (psvae_describe_plan(&d, buf, sizeof buf) != 0 || strcmp(buf, "untuned") != 0) return 4;
+    if (psvae_set_plan(&d, "garbage") != PSVAE_ERR_ARG) return 5;
+    if (psvae_train_step_f32(&d, NULL, NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, NULL, 1.0f, NULL, NULL, NULL, NULL,
+                             PSVAE_PHASE_ALL, NULL) != PSVAE_ERR_NULL) return 6;
+    printf("c abi ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "c_abi"
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(REPO, "include"), str(src),
+           "-o", str(exe), "-L", libdir, "-l:libpsvae_hip.so", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "c abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
