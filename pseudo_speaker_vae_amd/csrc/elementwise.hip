@@ -3,9 +3,30 @@
 // and the closed-form gradients of those pieces.  All HBM/L2-bound byte work:
 // 16 B per lane where alignment allows, one wavefront per row for the row reductions, fixed-order
 // two-stage reductions (bitwise reproducible; no float atomics).
+#include <hip/hip_bf16.h>
+
 #include "psvae_common.h"
 
 namespace psvae {
+
+// bf16 copies for the bf16 training pass: the elementwise kernels below can emit their result in both bf16 layouts
+// ([rows][cols] and [cols][rows padded to Bp]) so that no separate cast/transpose launch is needed
+__device__ __forceinline__ unsigned short f2bf_ew(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+struct Bf16Out {
+    unsigned short* rm[2];   // row-major [B, Z] outputs (nullable)
+    unsigned short* tr[2];   // transposed [Z, Bp] outputs (nullable)
+    int Z, Bp;
+};
+__device__ __forceinline__ void emit_bf16(const Bf16Out& o, int which, int64_t i, float v) {
+    if (o.rm[which] == nullptr) return;
+    const unsigned short b = f2bf_ew(v);
+    const int64_t row = i / o.Z, col = i - row * o.Z;
+    o.rm[which][i] = b;
+    o.tr[which][col * (int64_t)o.Bp + row] = b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011).  One lane = one Philox block = 4 normals for 4 consecutive
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict
                                                          const uint64_t* __restrict__ rng, uint64_t seed,
                                                          uint64_t offset, float* __restrict__ eps_out,
                                                          float* __restrict__ z, float* __restrict__ kl_partials,
-                                                         int64_t n, int vec_ok) {
+                                                         int64_t n, int vec_ok, const Bf16Out bo) {
     __shared__ float sh4[4];
     if (rng) { seed = rng[0]; offset = rng[1]; }
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -114,6 +135,8 @@ __global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict
             }
             *reinterpret_cast<f32x4*>(eps_out + e) = ep;
             *reinterpret_cast<f32x4*>(z + e) = zz;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) emit_bf16(bo, 0, e + i, zz[i]);
         } else {
             f32x4 ep = {0.f, 0.f, 0.f, 0.f};
             if (!eps_in) ep = philox_normal4(offset + (uint64_t)b, seed);
@@ -122,7 +145,9 @@ __global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict
                     const float ee = eps_in ? eps_in[e + i] : ep[i];
                     const float m = mu[e + i], l = lv[e + i];
                     eps_out[e + i] = ee;
-                    z[e + i] = m + expf(0.5f * l) * ee;
+                    const float zv = m + expf(0.5f * l) * ee;
+                    z[e + i] = zv;
+                    emit_bf16(bo, 0, e + i, zv);
                     kl += 1.0f + l - m * m - expf(l);
                 }
             }
@@ -480,14 +505,19 @@ __global__ __launch_bounds__(256) void reparam_bwd_final_kernel(
     const float* __restrict__ g_z, const float* __restrict__ mu, const float* __restrict__ lv,
     const float* __restrict__ eps, float beta, const float* __restrict__ go_p, float* __restrict__ g_mu,
     float* __restrict__ g_lv, int64_t n, int B, int D, const float* __restrict__ kl_partials, int n_kl,
-    const float* __restrict__ recon_partials, int n_recon, float* __restrict__ loss3, uint64_t* rng, uint64_t nblk) {
+    const float* __restrict__ recon_partials, int n_recon, float* __restrict__ loss3, uint64_t* rng, uint64_t nblk,
+    const Bf16Out bo) {
     __shared__ float sh4[4];
     const float go = go_p ? *go_p : 1.0f;
     const float kb = go * beta / (float)B;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gz = g_z[i], l = lv[i];
-        g_mu[i] = gz + kb * mu[i];
-        g_lv[i] = gz * eps[i] * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
+        const float gm = gz + kb * mu[i];
+        const float gl = gz * eps[i] * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
+        g_mu[i] = gm;
+        g_lv[i] = gl;
+        emit_bf16(bo, 0, i, gm);
+        emit_bf16(bo, 1, i, gl);
     }
     if (blockIdx.x == 0) {
         float k = 0.f, r = 0.f;
@@ -508,22 +538,29 @@ __global__ __launch_bounds__(256) void reparam_bwd_final_kernel(
 }
 
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng, uint64_t seed,
-                             uint64_t offset, float* eps_out, float* z, float* kl_partials, int64_t n, hipStream_t s) {
+                             uint64_t offset, float* eps_out, float* z, float* kl_partials, int64_t n, hipStream_t s,
+                             unsigned short* zb, unsigned short* zbT, int Z, int Bp) {
     const int vec_ok = al16(mu) && al16(lv) && al16(eps_out) && al16(z) && (!eps_in || al16(eps_in));
     if (eps_in) rng = nullptr;
+    Bf16Out bo{};
+    bo.rm[0] = zb; bo.tr[0] = zbT; bo.Z = Z > 0 ? Z : 1; bo.Bp = Bp;
     hipLaunchKernelGGL(reparam_kl_kernel, dim3(reparam_blocks(n)), dim3(256), 0, s, mu, lv, eps_in, rng, seed, offset,
-                       eps_out, z, kl_partials, n, vec_ok);
+                       eps_out, z, kl_partials, n, vec_ok, bo);
     return hipGetLastError();
 }
 
 hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps, float beta,
                                     const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
                                     const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
-                                    float* loss3, uint64_t* rng, hipStream_t s) {
+                                    float* loss3, uint64_t* rng, hipStream_t s, unsigned short* const* bf_rm,
+                                    unsigned short* const* bf_tr, int Bp) {
     const int64_t n = (int64_t)B * Z;
+    Bf16Out bo{};
+    if (bf_rm) { bo.rm[0] = bf_rm[0]; bo.rm[1] = bf_rm[1]; bo.tr[0] = bf_tr[0]; bo.tr[1] = bf_tr[1]; }
+    bo.Z = Z; bo.Bp = Bp;
     hipLaunchKernelGGL(reparam_bwd_final_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g_z, mu, lv, eps, beta, go,
                        g_mu, g_lv, n, B, D, kl_partials, n_kl, recon_partials, n_recon, loss3, rng,
-                       (uint64_t)((n + 3) / 4));
+                       (uint64_t)((n + 3) / 4), bo);
     return hipGetLastError();
 }
 

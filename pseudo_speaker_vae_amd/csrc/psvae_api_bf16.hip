@@ -151,13 +151,9 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
         addb(b, dm); addb(b, ds);
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
+    // reparameterisation + KL partials; the kernel also writes z in both bf16 layouts (no cast/transpose launch)
     RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
-                             (int64_t)B * Z, s));
-    {
-        const float* src[1] = {z_out}; u16* dst[1] = {sc.zb}; u16* dstT[1] = {sc.zbT};
-        int R[1] = {B}, C[1] = {Z}, ld[1] = {Z}, ldt[1] = {Bp};
-        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 1, s));
-    }
+                             (int64_t)B * Z, s, sc.zb, sc.zbT, Z, Bp));
     {
         GemmBatchBf b{};
         addb(b, hidden(sc.zb, Z, 6, sc.d1, sc.d1T, has_cond ? cond->tab[2] : nullptr));
@@ -214,13 +210,12 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
         addb(b, gz);
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
-    RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
-                                    sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
-                                    eps_in ? nullptr : rng_state, s));
-    {
-        const float* src[2] = {sc.gmu_f, sc.glv_f}; u16* dst[2] = {sc.gmu, sc.glv}; u16* dstT[2] = {sc.gmuT, sc.glvT};
-        int R[2] = {B, B}, C[2] = {Z, Z}, ld[2] = {Z, Z}, ldt[2] = {Bp, Bp};
-        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 2, s));
+    {   // g_mu / g_logvar (+ loss finalize, rng advance); the kernel also writes them in both bf16 layouts
+        u16* rm[2] = {sc.gmu, sc.glv};
+        u16* tr[2] = {sc.gmuT, sc.glvT};
+        RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
+                                        sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
+                                        eps_in ? nullptr : rng_state, s, rm, tr, Bp));
     }
     {
         GemmBatchBf b{};

@@ -156,7 +156,8 @@ hipError_t launch_reparam_linear(const float* mu, const float* lv, const float* 
                                  float* z_out, float* Y, float* kl_partials, int B, int Z, int N, hipStream_t s);
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
                              uint64_t seed, uint64_t offset, float* eps_out, float* z, float* kl_partials,
-                             int64_t n, hipStream_t s);
+                             int64_t n, hipStream_t s, unsigned short* zb = nullptr, unsigned short* zbT = nullptr,
+                             int Z = 0, int Bp = 0);  // zb / zbT: optional bf16 copies of z, [B,Z] and [Z,Bp]
 // row L2 normalise: xh = y / max(||y||, 1e-12), ynorm = that max
 hipError_t launch_normalize_rows(const float* y, float* xh, float* ynorm, int B, int D, hipStream_t s);
 // loss3 = {total, recon, kl}
@@ -176,7 +177,9 @@ hipError_t launch_reparam_bwd(const float* g_z, const float* mu, const float* lv
 hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps,
                                     float beta, const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
                                     const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
-                                    float* loss3, uint64_t* rng, hipStream_t s);
+                                    float* loss3, uint64_t* rng, hipStream_t s,
+                                    unsigned short* const* bf_rm = nullptr, unsigned short* const* bf_tr = nullptr,
+                                    int Bp = 0);  // bf_rm / bf_tr: optional bf16 copies of {g_mu, g_lv}: [B,Z] / [Z,Bp]
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);
