@@ -654,10 +654,10 @@ hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int np
 // cross-workgroup split-K: sum the partial slabs of up to 18 gradient tensors in fixed order
 // ---------------------------------------------------------------------------------------------
 struct SlabReduceArgs {
-    const float* src[18];
-    float* dst[18];
-    long long numel[18];
-    int S[18];
+    const float* src[24];
+    float* dst[24];
+    long long numel[24];
+    int S[24];
     int n;
 };
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs a) {
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs a
 hipError_t launch_slab_reduce(const float* const* src, float* const* dst, const int64_t* numel, const int* S, int n,
                               hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    if (n > 24) return hipErrorInvalidValue;
     SlabReduceArgs a{};
     long long mx = 0;
     for (int i = 0; i < n; ++i) {

@@ -40,7 +40,7 @@ __device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned
 // lines per 8 lanes) instead of every wave fetching its own fragments -- at these sizes the bf16 GEMMs are pure
 // operand traffic (the MFMAs of a 2-GFLOP launch take 1 us), so bytes per workgroup decide the time.
 template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED>
-__device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int tn, float* __restrict__ smem) {
+__device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     constexpr int NW = WM * WN * KS;
     static_assert(NW == 4, "4 waves per workgroup");
     constexpr int NT = 256;
@@ -101,11 +101,18 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                 *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[i];
             }
         };
-        const int nt = (K + BK - 1) / BK;
-        gload(0);
-        lstore(0);
+        // k tiles of this workgroup: all of them, or slice ksg of a cross-workgroup split (weight gradients)
+        const int nt_all = (K + BK - 1) / BK;
+        const int S = d.ksplit > 1 ? d.ksplit : 1;
+        const int per = (nt_all + S - 1) / S;
+        const int t_beg = ksg * per;
+        const int nt = (t_beg + per < nt_all ? t_beg + per : nt_all);  // end (exclusive)
+        if (t_beg < nt) {
+            gload(t_beg);
+            lstore(t_beg & 1);
+        }
         __syncthreads();
-        for (int t = 0; t < nt; ++t) {
+        for (int t = t_beg; t < nt; ++t) {
             const int buf = t & 1;
             if (t + 1 < nt) gload(t + 1);  // in flight under this tile's MFMAs
 #pragma unroll
@@ -284,7 +291,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                 }
             }
             if (d.Cf) {  // fp32 output (final outputs, wgrads)
-                float* p = d.Cf + (size_t)row * d.ldcf + col;
+                float* p = d.Cf + (size_t)ksg * M * d.ldcf + (size_t)row * d.ldcf + col;  // ksplit: this slice's slab
                 if (colfull && ((d.ldcf & 3) == 0)) {
                     stgb<f32x4>(p, v);
                 } else {
@@ -368,7 +375,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         float s = csum_s[tid];
 #pragma unroll
         for (int k2 = 1; k2 < KS; ++k2) s += csum_s[k2 * BM + tid];
-        if (m0 + tid < M) stgb<float>(d.colsum + m0 + tid, s);
+        if (m0 + tid < M) stgb<float>(d.colsum + (size_t)ksg * M + m0 + tid, s);
     }
 }
 
@@ -380,9 +387,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch)
     for (int i = 1; i < batch.n; ++i)
         if (tile >= batch.d[i].tile_begin) di = i;
     const GemmDescBf& d = batch.d[di];
-    const int lt = tile - d.tile_begin;
+    int lt = tile - d.tile_begin;
+    const int tiles_mn = d.tiles_m * d.tiles_n;
+    const int ksg = STAGED ? lt / tiles_mn : 0;  // cross-workgroup k slice (staged kernel only)
+    lt -= ksg * tiles_mn;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    gemm_tile_bf16<TM, TN, WM, WN, KS, D, STAGED>(d, tm, tn, smem);
+    gemm_tile_bf16<TM, TN, WM, WN, KS, D, STAGED>(d, tm, tn, ksg, smem);
 }
 
 template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED = false>
@@ -396,7 +406,9 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
         b.d[i].tiles_m = (b.d[i].M + BM - 1) / BM;
         b.d[i].tiles_n = (b.d[i].N + BN - 1) / BN;
         b.d[i].tile_begin = t;
-        t += b.d[i].tiles_m * b.d[i].tiles_n;
+        const int S = (STAGED && b.d[i].ksplit > 1) ? b.d[i].ksplit : 1;
+        if (!STAGED && b.d[i].ksplit > 1) return hipErrorInvalidValue;  // only the staged kernel splits k over workgroups
+        t += b.d[i].tiles_m * b.d[i].tiles_n * S;
     }
     b.total_tiles = t;
     static bool attr_done = false;
@@ -419,15 +431,20 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
 // bottleneck: 64x64 per wave halves the bytes per MFMA of 32x32); k split only when the tile count is low
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
-    long t44 = 0, t22 = 0;
+    long t44 = 0, t22 = 0, t88 = 0;
     int kmax = 0;
     for (int i = 0; i < b.n; ++i) {
+        t88 += (long)((b.d[i].M + 127) / 128) * ((b.d[i].N + 127) / 128);
         t44 += (long)((b.d[i].M + 63) / 64) * ((b.d[i].N + 63) / 64);
         t22 += (long)((b.d[i].M + 31) / 32) * ((b.d[i].N + 31) / 32);
         kmax = b.d[i].K > kmax ? b.d[i].K : kmax;
     }
     const char* bm = getenv("PSVAE_BF16_BIG_MIN");  // tuning / tests (read per call: a test flips it in-process)
     const int big_min = bm ? atoi(bm) : 2048;
+    if (b.force_staged) return launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream);  // backward of a large batch (see the API)
+    static const int t88_min = getenv("PSVAE_BF16_T88_MIN") ? atoi(getenv("PSVAE_BF16_T88_MIN")) : 256;
+    if (t88_min > 0 && t88 >= t88_min && kmax <= 1024)  // a full machine of 128x128 tiles: half the operand bytes of 64x64
+        return launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream);
     if (t44 >= 192) {
         const char* st = getenv("PSVAE_BF16_STAGED");
         const int staged = st ? atoi(st) : 1;

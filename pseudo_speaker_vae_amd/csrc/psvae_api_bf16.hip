@@ -16,6 +16,18 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
         if (_e != hipSuccess) return (int)_e; \
     } while (0)
 
+// Large batches (B >= 2048): every backward launch uses the LDS-staged 128x128 kernel (half the operand bytes per FLOP of
+// the 64x64 tiles: the bf16 GEMMs are pure operand traffic), and the weight gradients, which have only 16 such tiles,
+// cut the batch over S workgroups per tile; the fp32 partial slabs are summed in fixed order by one launch at the end.
+constexpr int BF_SMAX = 8;
+inline int bf_wgrad_split(int Bp) {
+    const char* e = getenv("PSVAE_BF16_WGRAD_S");  // tuning / tests (0 = the 64x64 k-split-4 path for every batch size)
+    if (e) { const int v = atoi(e); return v < 0 ? 0 : (v > BF_SMAX ? BF_SMAX : v); }
+    if (Bp < 2048) return 0;
+    const int s = Bp / 512;
+    return s > BF_SMAX ? BF_SMAX : s;
+}
+
 struct BfScratch {
     // weights: row-major bf16 copies Wb[i] ([out,in]) and transposed WbT[i] ([in,out]) of the 9 matrices
     u16 *Wb[9], *WbT[9];
@@ -27,6 +39,8 @@ struct BfScratch {
     u16 *gmu, *gmuT, *glv, *glvT;                   // [B,Z] / [Z,Bp]
     u16* ohT;                                       // [6,Bp] one-hot labels, transposed
     float *gz, *gmu_f, *glv_f, *kl_partials, *recon_partials;
+    // large batches: weight-gradient partials of the cross-workgroup split (BF_SMAX slices each), summed at the end
+    float *slab_w[9], *slab_b[9], *slab_t[3];
     int n_recon_max;
     size_t bytes;
 };
@@ -67,6 +81,11 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
     s.kl_partials = tf((size_t)reparam_blocks(B * Z));
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));
     s.recon_partials = tf((size_t)s.n_recon_max);
+    for (int k = 0; k < 9; ++k) {
+        s.slab_w[k] = tf((size_t)BF_SMAX * wo[k] * wi[k]);
+        s.slab_b[k] = tf((size_t)BF_SMAX * wo[k]);
+    }
+    for (int k = 0; k < 3; ++k) s.slab_t[k] = tf((size_t)BF_SMAX * PSVAE_COND_DIM * H);
     s.bytes = off;
     return s;
 }
@@ -178,9 +197,19 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     }
     // backward: wgrad  dW[o][i] = sum_b dY^T[o][b] X^T[i][b]  (A = dY^T [out,Bp], B = X^T [in,Bp], fp32 out, colsum = db)
     //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]     (A = dY [B,out],  B = W^T [in,out], masked, both bf16 layouts)
-    auto wgrad = [&](const u16* dYT, int out_, const u16* XT, int in_, float* dW, float* db) {
+    const int S = bf_wgrad_split(Bp);  // 0: small batch, 64x64 tiles with the k split inside the workgroup
+    const float* rsrc[24]; float* rdst[24]; int64_t rnum[24]; int rS[24]; int nred = 0;
+    auto wgrad = [&](const u16* dYT, int out_, const u16* XT, int in_, float* dW, float* db, float* slabW, float* slabB) {
         GemmDescBf d = bdesc(out_, in_, Bp, dYT, Bp, XT, Bp);
-        d.Cf = dW; d.ldcf = in_; d.colsum = db;
+        d.ldcf = in_;
+        if (S > 0) {
+            d.ksplit = S;
+            d.Cf = slabW; d.colsum = db ? slabB : nullptr;
+            rsrc[nred] = slabW; rdst[nred] = dW; rnum[nred] = (int64_t)out_ * in_; rS[nred++] = S;
+            if (db) { rsrc[nred] = slabB; rdst[nred] = db; rnum[nred] = out_; rS[nred++] = S; }
+        } else {
+            d.Cf = dW; d.colsum = db;
+        }
         return d;
     };
     auto dgrad = [&](const u16* dY, int out_, int wk, int in_, u16* dX, u16* dXT, const u16* act) {
@@ -191,23 +220,26 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     };
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.gyT, D, sc.d2T, H, G[16], G[17]));
+        addb(b, wgrad(sc.gyT, D, sc.d2T, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
         addb(b, dgrad(sc.gy, D, 8, H, sc.dd2, sc.dd2T, sc.d2));
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dd2T, H, sc.d1T, H, G[14], G[15]));
+        addb(b, wgrad(sc.dd2T, H, sc.d1T, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
         addb(b, dgrad(sc.dd2, H, 7, H, sc.dd1, sc.dd1T, sc.d1));
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dd1T, H, sc.zbT, Z, G[12], G[13]));
-        if (has_cond) addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dd1T, H, cond->gtab[2], nullptr));  // table grad
+        addb(b, wgrad(sc.dd1T, H, sc.zbT, Z, G[12], G[13], sc.slab_w[6], sc.slab_b[6]));
+        if (has_cond) addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dd1T, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));  // table grad
         GemmDescBf gz = bdesc(B, Z, H, sc.dd1, H, sc.WbT[6], H);  // g_z in fp32
         gz.Cf = sc.gz; gz.ldcf = Z;
         addb(b, gz);
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {   // g_mu / g_logvar (+ loss finalize, rng advance); the kernel also writes them in both bf16 layouts
@@ -219,30 +251,34 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.gmuT, Z, sc.h2mT, H, G[4], G[5]));
-        addb(b, wgrad(sc.glvT, Z, sc.h2sT, H, G[10], G[11]));
+        addb(b, wgrad(sc.gmuT, Z, sc.h2mT, H, G[4], G[5], sc.slab_w[2], sc.slab_b[2]));
+        addb(b, wgrad(sc.glvT, Z, sc.h2sT, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
         addb(b, dgrad(sc.gmu, Z, 2, H, sc.dh2m, sc.dh2mT, sc.h2m));
         addb(b, dgrad(sc.glv, Z, 5, H, sc.dh2s, sc.dh2sT, sc.h2s));
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dh2mT, H, sc.h1mT, H, G[2], G[3]));
-        addb(b, wgrad(sc.dh2sT, H, sc.h1sT, H, G[8], G[9]));
+        addb(b, wgrad(sc.dh2mT, H, sc.h1mT, H, G[2], G[3], sc.slab_w[1], sc.slab_b[1]));
+        addb(b, wgrad(sc.dh2sT, H, sc.h1sT, H, G[8], G[9], sc.slab_w[4], sc.slab_b[4]));
         addb(b, dgrad(sc.dh2m, H, 1, H, sc.dh1m, sc.dh1mT, sc.h1m));
         addb(b, dgrad(sc.dh2s, H, 4, H, sc.dh1s, sc.dh1sT, sc.h1s));
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dh1mT, H, sc.xbT, D, G[0], G[1]));
-        addb(b, wgrad(sc.dh1sT, H, sc.xbT, D, G[6], G[7]));
+        addb(b, wgrad(sc.dh1mT, H, sc.xbT, D, G[0], G[1], sc.slab_w[0], sc.slab_b[0]));
+        addb(b, wgrad(sc.dh1sT, H, sc.xbT, D, G[6], G[7], sc.slab_w[3], sc.slab_b[3]));
         if (has_cond) {  // gtab[c][n] = sum_b onehot[b][c] dh1[b][n]: two more wgrad problems in this launch
-            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1mT, H, cond->gtab[0], nullptr));
-            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1sT, H, cond->gtab[1], nullptr));
+            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1mT, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
+            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1sT, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
         }
+        b.force_staged = S > 0;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
+    if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
     return 0;
 }
 

@@ -122,6 +122,8 @@ struct GemmDescBf {
     const int32_t* age;
     float scale;
     int M, N, K;                 // K % 32 == 0
+    int ksplit;                  // > 1 (LDS-staged 128x128 kernel only): the k range is cut over `ksplit` workgroups; slice s
+                                 // writes its partial fp32 tile to Cf + s*M*ldcf and partial column sums to colsum + s*M
     int lda, ldb, ldcf, ldcb, ldt, ldmask;
     int epi;
     int tiles_m, tiles_n, tile_begin;
@@ -130,6 +132,7 @@ struct GemmBatchBf {
     GemmDescBf d[MAX_GROUP];
     int n;
     int total_tiles;
+    int force_staged;  // host-side: 1 = launch with the LDS-staged 128x128 kernel whatever the tile count
 };
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream);
 hipError_t launch_cast_transpose(const float* const* src, unsigned short* const* dst, unsigned short* const* dstT,
@@ -183,7 +186,7 @@ hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const flo
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);
-// dst[i][e] = sum_{s < S[i]} src[i][s*numel[i] + e]   (fixed order: bitwise reproducible), up to 18 tensors
+// dst[i][e] = sum_{s < S[i]} src[i][s*numel[i] + e]   (fixed order: bitwise reproducible), up to 24 tensors
 hipError_t launch_slab_reduce(const float* const* src, float* const* dst, const int64_t* numel, const int* S, int n,
                               hipStream_t s);
 hipError_t launch_transpose_f32(const float* const* src, float* const* dst, const int* R, const int* C, int n,

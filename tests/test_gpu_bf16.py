@@ -22,17 +22,21 @@ def assert_close_bf16(a, b, what):
     assert rel_err(a, b) <= 6e-2, f"{what}: worst element {rel_err(a, b):.3e}"
 
 
-@pytest.fixture(params=["default-tiles", "lds-staged-128x128"])
+@pytest.fixture(params=["default-tiles", "lds-staged-128x128", "split-wgrad-3", "no-split"])
 def tile_mode(request, monkeypatch):
     """the 128x128 LDS-staged kernel normally starts at >= 2048 64x64 tiles; force it for forward / dgrad-only
     launches so the parity cases below cover both main loops (PSVAE_BF16_BIG_MIN is read per launch)"""
     if request.param == "lds-staged-128x128":
         monkeypatch.setenv("PSVAE_BF16_BIG_MIN", "1")
+    if request.param == "split-wgrad-3":  # the large-batch backward (weight gradients cut over 3 workgroups per tile,
+        monkeypatch.setenv("PSVAE_BF16_WGRAD_S", "3")  # some slices empty at small B) forced at every size
+    if request.param == "no-split":       # ... and switched off at every size (B = 4096 uses it by default)
+        monkeypatch.setenv("PSVAE_BF16_WGRAD_S", "0")
     return request.param
 
 
 @pytest.mark.parametrize("D,Z,B,cond", [(256, 64, 4096, True), (256, 64, 1024, False), (256, 64, 100, True),
-                                        (512, 128, 64, False)])
+                                        (512, 128, 64, False), (256, 64, 2100, True)])
 def test_bf16_train_step_matches_emulation(D, Z, B, cond, tile_mode):
     from pseudo_speaker_vae_amd import _ffi, ops
     p = O.init_params(D, Z, 1)
