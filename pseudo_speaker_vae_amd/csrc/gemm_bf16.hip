@@ -463,10 +463,28 @@ struct CastArgs {
     u16* dstT[12];
     int R[12], Cc[12], ld[12], ldt[12], tile_begin[12];
     int n;
+    // optional rider: the transposed one-hot label matrix ohT[6][Bp] (blocks past the cast tiles)
+    int cast_tiles;
+    const int32_t* gender;
+    const int32_t* age;
+    u16* ohT;
+    int B, Bp;
 };
 
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const CastArgs a) {
     __shared__ float tile[32][33];
+    if ((int)blockIdx.x >= a.cast_tiles) {  // one-hot rider blocks (one launch fewer per step)
+        const int b = ((int)blockIdx.x - a.cast_tiles) * 256 + threadIdx.x;
+        if (b < a.Bp) {
+            const int g = b < a.B ? a.gender[b] : -1, ag = b < a.B ? a.age[b] : -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.ohT[(size_t)c * a.Bp + b] = (g == c) ? (u16)0x3F80 : (u16)0;
+                a.ohT[(size_t)(3 + c) * a.Bp + b] = (ag == c) ? (u16)0x3F80 : (u16)0;
+            }
+        }
+        return;
+    }
     int pi = 0;
     for (int i = 1; i < a.n; ++i)
         if ((int)blockIdx.x >= a.tile_begin[i]) pi = i;
@@ -496,7 +514,8 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const CastArgs a) {
 }
 
 hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* const* dstT, const int* R, const int* Cc,
-                                 const int* ld, const int* ldt, int n, hipStream_t s) {
+                                 const int* ld, const int* ldt, int n, hipStream_t s, const int32_t* gender,
+                                 const int32_t* age, u16* ohT, int B, int Bp) {
     CastArgs a{};
     int t = 0;
     for (int i = 0; i < n; ++i) {
@@ -506,6 +525,11 @@ hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* 
         t += ((R[i] + 31) / 32) * ((Cc[i] + 31) / 32);
     }
     a.n = n;
+    a.cast_tiles = t;
+    if (ohT) {
+        a.gender = gender; a.age = age; a.ohT = ohT; a.B = B; a.Bp = Bp;
+        t += (Bp + 255) / 256;
+    }
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(t), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -133,7 +133,6 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     int wo[9], wi[9];
     weight_dims(D, Z, wo, wi);
 
-    if (has_cond) RET_IF(launch_onehot_t(cond->gender, cond->age, sc.ohT, B, Bp, s));
     {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
@@ -141,7 +140,9 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
             R[k] = wo[k]; C[k] = wi[k]; ld[k] = wi[k]; ldt[k] = wo[k];
         }
         src[9] = x; dst[9] = sc.xb; dstT[9] = sc.xbT; R[9] = B; C[9] = D; ld[9] = D; ldt[9] = Bp;
-        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s));
+        // (+ the transposed one-hot label matrix for the conditional-table gradients, as rider blocks)
+        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
+                                     has_cond ? cond->age : nullptr, has_cond ? sc.ohT : nullptr, B, Bp));
     }
     auto hidden = [&](const u16* A, int K, int wk, u16* out, u16* outT, const float* ctab) {
         GemmDescBf d = bdesc(B, H, K, A, K, sc.Wb[wk], K);

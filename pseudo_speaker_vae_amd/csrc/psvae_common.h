@@ -136,7 +136,9 @@ struct GemmBatchBf {
 };
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream);
 hipError_t launch_cast_transpose(const float* const* src, unsigned short* const* dst, unsigned short* const* dstT,
-                                 const int* R, const int* C, const int* ld, const int* ldt, int n, hipStream_t s);
+                                 const int* R, const int* C, const int* ld, const int* ldt, int n, hipStream_t s,
+                                 const int32_t* gender = nullptr, const int32_t* age = nullptr,
+                                 unsigned short* ohT = nullptr, int B = 0, int Bp = 0);
 hipError_t launch_onehot_t(const int32_t* gender, const int32_t* age, unsigned short* ohT, int B, int Bp, hipStream_t s);
 hipError_t launch_cond_colsum_bf16(const unsigned short* const* dY, float* const* gtab, int nprob,
                                    const int32_t* gender, const int32_t* age, int B, int N, hipStream_t s);
