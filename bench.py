@@ -76,10 +76,14 @@ def bench_decode(args, world, rank, dev):
         from pseudo_speaker_vae_amd import _ffi
         _ffi.check(_ffi.lib().psvae_philox_normal_f32(z.data_ptr(), n * Z, 1234 + rank, i * ((n * Z + 3) // 4),
                                                       torch.cuda.current_stream().cuda_stream), "philox")
-        ops.decode(z, dec, D, out=out, scratch=step.scratch)
-    import ctypes
+        if bf16:
+            ops.decode_bf16(z, dec, D, out=out, scratch=step.scratch)
+        else:
+            ops.decode(z, dec, D, out=out, scratch=step.scratch)
     from pseudo_speaker_vae_amd import _ffi
-    step.scratch = torch.empty(int(_ffi.lib().psvae_decode_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    bf16 = args.dtype == "bf16"
+    nbytes = _ffi.lib().psvae_decode_bf16_scratch_bytes(n, D, Z) if bf16 else _ffi.lib().psvae_decode_scratch_bytes(n)
+    step.scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
 
     def fence():
         if world > 1:
@@ -111,12 +115,14 @@ def bench_decode(args, world, rank, dev):
             "metric": "speaker-embeddings/sec (decode)", "value": round(n * world * steps / wall, 1),
             "unit": "speaker-embeddings/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"cfg5: decode-only sampling, {n * world} rows per step ({n}/GPU), d_in={D} z={Z}, "
-                                   "Philox z on device + 3-layer decoder", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "flop_per_embedding": fpe}}), flush=True)
+                                   "Philox z on device + 3-layer decoder"
+                                   + (" (bf16 operands / fp32 accumulate)" if bf16 else ""), "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3),
+                         "peak": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS), 4),
+                         "traffic": None, "flop_per_embedding": fpe}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

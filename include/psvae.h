@@ -170,6 +170,11 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
 /* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
  * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
 size_t psvae_decode_scratch_bytes(int64_t N);
+/* bf16 variant: bf16 operands and hidden activations, fp32 accumulation / biases / x_hat; Z % 32 == 0,
+ * D % 4 == 0; no conditional tables.  About 8-bit-mantissa accuracy on x_hat (see tests/test_gpu_bf16.py). */
+size_t psvae_decode_bf16_scratch_bytes(int64_t N, int64_t D, int64_t Z);
+int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6, float* x_hat,
+                      void* scratch, uint32_t flags, void* stream);
 int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6,
                      const float* cond_tab /* nullable [6,512] */, const int32_t* gender,
                      const int32_t* age, float* x_hat, void* scratch, uint32_t flags, void* stream);

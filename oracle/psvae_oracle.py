@@ -463,6 +463,16 @@ def bf(t: torch.Tensor) -> torch.Tensor:
     return t.bfloat16().float()
 
 
+def decode_bf16(p, z, normalize_decoder: bool = False):
+    """bf16 emulation of VAEModel.decode (model.py:65-69): bf16 operands (z, weights, hidden activations), fp32
+    accumulation, biases and output -- the rounding points of psvae_decode_bf16"""
+    W = {k: bf(v) for k, v in p.items() if k.startswith("decoder") and k.endswith("weight")}
+    d1 = bf(torch.relu(bf(z) @ W["decoder.0.weight"].t() + p["decoder.0.bias"]))
+    d2 = bf(torch.relu(d1 @ W["decoder.2.weight"].t() + p["decoder.2.bias"]))
+    y = d2 @ W["decoder.4.weight"].t() + p["decoder.4.bias"]
+    return normalize_rows(y)[0] if normalize_decoder else y
+
+
 def train_step_bf16(p, x, eps, beta: float = 1.0, go: float = 1.0, tabs=None, gender=None, age=None):
     B, D = x.shape
     W = {k: bf(v) for k, v in p.items() if k.endswith("weight")}

@@ -283,4 +283,70 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     return 0;
 }
 
+// ---- decode-only sampling in bf16 (VAEModel.decode, model.py:65-69; SURVEY 8b psvae_decode_bf16) ----------------
+// Every GEMM reads its activation row-major, so this path needs no second layout: z and the three decoder weights are
+// cast to bf16 (one launch per call / per chunk), the hidden activations stay bf16, biases, accumulation and x_hat fp32.
+static const int64_t DECODE_CHUNK_BF = 131072;
+
+size_t psvae_decode_bf16_scratch_bytes(int64_t N, int64_t D, int64_t Z) {
+    if (N <= 0 || D <= 0 || Z <= 0) return 0;
+    const int64_t c = N < DECODE_CHUNK_BF ? N : DECODE_CHUNK_BF;
+    return align_up((size_t)(H * Z + H * H + D * H) * 2, 256) + align_up((size_t)c * Z * 2, 256) +
+           2 * align_up((size_t)c * H * 2, 256) + align_up((size_t)c * sizeof(float), 256);
+}
+
+int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6, float* x_hat,
+                      void* scratch, uint32_t flags, void* stream) {
+    if (N <= 0 || D <= 0 || Z <= 0) return PSVAE_ERR_SHAPE;
+    if ((Z & 31) || (D & 3)) return PSVAE_ERR_SHAPE;  // contracted dims are whole 32-k chunks; 16-B fp32 output rows
+    if (!z || !dec6 || !x_hat || !scratch) return PSVAE_ERR_NULL;
+    for (int i = 0; i < 6; ++i)
+        if (!dec6[i]) return PSVAE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t c = N < DECODE_CHUNK_BF ? N : DECODE_CHUNK_BF;
+    char* base = reinterpret_cast<char*>(scratch);
+    u16* Wb0 = reinterpret_cast<u16*>(base);            // [H, Z]
+    u16* Wb1 = Wb0 + (size_t)H * Z;                     // [H, H]
+    u16* Wb2 = Wb1 + (size_t)H * H;                     // [D, H]
+    size_t off = align_up((size_t)(H * Z + H * H + D * H) * 2, 256);
+    u16* zb = reinterpret_cast<u16*>(base + off); off += align_up((size_t)c * Z * 2, 256);
+    u16* d1 = reinterpret_cast<u16*>(base + off); off += align_up((size_t)c * H * 2, 256);
+    u16* d2 = reinterpret_cast<u16*>(base + off); off += align_up((size_t)c * H * 2, 256);
+    float* yn = reinterpret_cast<float*>(base + off);
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
+    for (int64_t r0 = 0; r0 < N; r0 += c) {
+        const int n = (int)((N - r0) < c ? (N - r0) : c);
+        {   // casts: the chunk of z, and (first chunk only) the three weights
+            const float* src[4] = {z + r0 * Z, dec6[0], dec6[2], dec6[4]};
+            u16* dst[4] = {zb, Wb0, Wb1, Wb2};
+            u16* dstT[4] = {nullptr, nullptr, nullptr, nullptr};
+            int R[4] = {n, H, H, (int)D}, C[4] = {(int)Z, (int)Z, H, H}, ld[4] = {(int)Z, (int)Z, H, H}, ldt[4] = {0, 0, 0, 0};
+            RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, r0 == 0 ? 4 : 1, s));
+        }
+        {
+            GemmBatchBf b{};
+            GemmDescBf d = bdesc(n, H, (int)Z, zb, (int)Z, Wb0, (int)Z);
+            d.bias = dec6[1]; d.epi = BEPI_RELU; d.Cb = d1; d.ldcb = H;
+            addb(b, d);
+            RET_IF(launch_gemm_batch_bf16(b, s));
+        }
+        {
+            GemmBatchBf b{};
+            GemmDescBf d = bdesc(n, H, H, d1, H, Wb1, H);
+            d.bias = dec6[3]; d.epi = BEPI_RELU; d.Cb = d2; d.ldcb = H;
+            addb(b, d);
+            RET_IF(launch_gemm_batch_bf16(b, s));
+        }
+        {
+            GemmBatchBf b{};
+            GemmDescBf d = bdesc(n, (int)D, H, d2, H, Wb2, H);
+            d.bias = dec6[5]; d.Cf = x_hat + r0 * D; d.ldcf = (int)D;
+            addb(b, d);
+            RET_IF(launch_gemm_batch_bf16(b, s));
+        }
+        if (normalize) RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+    }
+    return 0;
+}
+
 }  // extern "C"

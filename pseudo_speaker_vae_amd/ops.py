@@ -228,6 +228,21 @@ def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: i
     return xh
 
 
+def decode_bf16(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
+                out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """VAEModel.decode with bf16 operands / fp32 accumulation (psvae_decode_bf16): the fast sampling mode"""
+    z = _f32(z, "z")
+    N, Z = z.shape
+    xh = out if out is not None else torch.empty(N, D, dtype=torch.float32, device=z.device)
+    nbytes = int(_ffi.lib().psvae_decode_bf16_scratch_bytes(N, D, Z))
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+    arr = (C.c_void_p * 6)(*[_ffi.ptr(_f32(t, "decoder param")) for t in dec_params])
+    _ffi.check(_ffi.lib().psvae_decode_bf16(N, D, Z, _ffi.ptr(z), arr, _ffi.ptr(xh), _ffi.ptr(scratch), flags,
+                                            _ffi.stream_ptr()), "decode_bf16")
+    return xh
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
               weight_decay: float = 0.0, grad_scale: float = 1.0):
     n = param.numel()

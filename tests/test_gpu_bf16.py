@@ -90,3 +90,21 @@ def test_bf16_rejects_unsupported_dims():
         ws = ops.Bf16Workspace(B, D, Z, DEV)
         ops.train_step_bf16(ws, torch.randn(B, D, device=DEV), params, [torch.empty_like(t) for t in params],
                             torch.empty(3, device=DEV))
+
+
+@pytest.mark.parametrize("D,Z,N,normalize", [(256, 64, 1000, False), (256, 64, 70000, False), (512, 128, 300, True)])
+def test_bf16_decode_matches_emulation(D, Z, N, normalize):
+    """psvae_decode_bf16 against the oracle's bf16 emulation of VAEModel.decode (same rounding points), and within
+    bf16 accuracy of the fp32 decode"""
+    from pseudo_speaker_vae_amd import _ffi, ops
+    p = O.init_params(D, Z, 2)
+    torch.manual_seed(N)
+    z = torch.randn(N, Z)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    flags = _ffi.NORMALIZE_DECODER if normalize else 0
+    got = ops.decode_bf16(z.to(DEV), dec, D, flags=flags)
+    torch.cuda.synchronize()
+    ref = O.decode_bf16(p, z, normalize)
+    assert_close(got.cpu(), ref, BF16_TOL, "x_hat vs bf16 emulation")
+    full = ops.decode(z.to(DEV), dec, D, flags=flags)
+    assert rel_err(got.cpu(), full.cpu()) <= 3e-2, "bf16 decode vs fp32 decode"

@@ -62,3 +62,17 @@ if "--decode" in sys.argv:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print(f"stock PyTorch decode 1M rows: {ms:7.2f} ms = {N / ms / 1e3:.1f} M embeddings/s")
+    # same decode with bf16 weights / activations (stock PyTorch, for psvae_decode_bf16's context)
+    decb = dec.to(torch.bfloat16)
+    zsb = zs.to(torch.bfloat16)
+    outb = torch.empty(N, D, device=dev)
+    def decode_all_bf16():
+        with torch.no_grad():
+            for r0 in range(0, N, 131072):
+                outb[r0:r0 + 131072] = decb(zsb[r0:r0 + 131072]).float()
+    decode_all_bf16(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5): decode_all_bf16()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"stock PyTorch bf16 decode 1M rows (z already bf16): {ms:7.2f} ms = {N / ms / 1e3:.1f} M embeddings/s")
