@@ -200,6 +200,19 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
                        float noise_weight, int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
                        float* history, void* stream);
 
+/* The two halves of psvae_train_step_bf16 as separate calls (a validation step runs only the first).  The forward leaves
+ * the bf16 activations, the MSE gradient (already times *grad_loss) and the loss partial sums in `scratch`; the backward
+ * must be given the same scratch, x, params, cond, eps_out, mu and logvar, untouched.  rng_state (nullable) supplies
+ * {seed, offset} to the forward and is advanced by the backward. */
+int psvae_forward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                       const float* eps_in, uint64_t seed, uint64_t offset, const uint64_t* rng_state, float* eps_out,
+                       float* z_out, float* x_hat, float* mu, float* logvar, const float* grad_loss, void* scratch,
+                       void* stream);
+int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                        uint64_t* rng_state, float* eps_out, float* z_out, float* x_hat, float* mu, float* logvar,
+                        float beta, const float* grad_loss, const psvae_grads* grads, float* loss3, void* scratch,
+                        void* stream);
+
 /* LatentClassifier training step on latent rows (latent_classifier.py:7-70 as used at lightning.py:73-98):
  * logits = W1 z + b1 (hidden == 0) or W2 relu(W1 z + b1) + b2; loss2 = {mean cross entropy against y, number of rows
  * whose argmax equals the label}; g_z[B,Z] and the parameter gradients are d(mean CE)/d(.) times grad_scale

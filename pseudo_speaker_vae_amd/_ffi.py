@@ -28,7 +28,7 @@ SYMBOLS = (
     "psvae_version", "psvae_debug_force_tile", "psvae_debug_force_wgrad_split", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
     "psvae_tune_train_step_f32", "psvae_describe_plan", "psvae_set_plan",
-    "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16",
+    "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
 )
@@ -114,6 +114,11 @@ def lib() -> C.CDLL:
     L.psvae_decode_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_decode_bf16.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, u32, vp]
     L.psvae_decode_bf16.restype = C.c_int
+    L.psvae_forward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.psvae_forward_bf16.restype = C.c_int
+    L.psvae_backward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, f32, vp,
+                                      C.POINTER(Grads), vp, vp, vp]
+    L.psvae_backward_bf16.restype = C.c_int
     L.psvae_gather_rows_f32.argtypes = [vp, i64, i64, vp, i64, vp, vp]
     L.psvae_gather_rows_f32.restype = C.c_int
     f64 = C.c_double

@@ -110,29 +110,32 @@ size_t psvae_bf16_scratch_bytes(const psvae_dims* dims) {
 // One training pass in bf16 (config 3).  x, params, grads, loss3, x_hat, mu, logvar are fp32; every
 // intermediate lives in `scratch` (psvae_bf16_scratch_bytes; MUST be zero-filled once by the caller: the
 // batch padding of the transposed copies is read but never written).  D and Z must be multiples of 32.
-int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
-                          const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
-                          float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
-                          const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
-    if (!dims || !x || !params || !grads || !x_hat || !mu || !logvar || !loss3 || !scratch || !eps_out || !z_out)
-        return PSVAE_ERR_NULL;
+// mode: 1 = forward (everything up to x_hat, the MSE gradient and the loss partial sums), 2 = backward, 3 = both
+static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                     const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
+                     float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
+                     const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
+    const bool fwd = mode & 1, bwd = mode & 2;
+    if (!dims || !x || !params || !x_hat || !mu || !logvar || !scratch || !eps_out || !z_out) return PSVAE_ERR_NULL;
+    if (bwd && (!grads || !loss3)) return PSVAE_ERR_NULL;
     if (dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return PSVAE_ERR_SHAPE;
     if ((dims->D & 31) || (dims->Z & 31)) return PSVAE_ERR_SHAPE;  // contracted dims must be whole 32-k chunks
     for (int i = 0; i < PSVAE_NPARAM; ++i)
-        if (!params->p[i] || !grads->g[i]) return PSVAE_ERR_NULL;
+        if (!params->p[i] || (bwd && !grads->g[i])) return PSVAE_ERR_NULL;
     const bool has_cond = cond && cond->tab[0];
-    if (has_cond && (!cond->gender || !cond->age || !cond->tab[1] || !cond->tab[2] || !cond->gtab[0] ||
-                     !cond->gtab[1] || !cond->gtab[2]))
-        return PSVAE_ERR_NULL;
+    if (has_cond && (!cond->gender || !cond->age || !cond->tab[1] || !cond->tab[2])) return PSVAE_ERR_NULL;
+    if (has_cond && bwd && (!cond->gtab[0] || !cond->gtab[1] || !cond->gtab[2])) return PSVAE_ERR_NULL;
     const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
     const int Bp = (B + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     const float* const* P = params->p;
-    float* const* G = grads->g;
+    float* const* G = bwd ? grads->g : nullptr;
     BfScratch sc = carve_bf(scratch, B, D, Z);
     int wo[9], wi[9];
     weight_dims(D, Z, wo, wi);
 
+    int n_recon = sc.n_recon_max;  // backward-only call: every slot (the forward-only call zeroed the unused ones)
+    if (fwd) {
     {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
@@ -184,7 +187,8 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
         addb(b, hidden(sc.d1, H, 7, sc.d2, sc.d2T, nullptr));
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
-    int n_recon = 0;
+    if (!bwd)  // forward-only call: the backward call sums ALL partial slots, so the unused ones must be zero
+        RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
     {  // decoder output (fp32) + MSE gradient (bf16, both layouts) + MSE partial sums
         GemmBatchBf b{};
         GemmDescBf d = bdesc(B, D, H, sc.d2, H, sc.Wb[8], H);
@@ -196,6 +200,8 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
         n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
         if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
     }
+    }
+    if (!bwd) return 0;
     // backward: wgrad  dW[o][i] = sum_b dY^T[o][b] X^T[i][b]  (A = dY^T [out,Bp], B = X^T [in,Bp], fp32 out, colsum = db)
     //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]     (A = dY [B,out],  B = W^T [in,out], masked, both bf16 layouts)
     const int S = bf_wgrad_split(Bp);  // 0: small batch, 64x64 tiles with the k split inside the workgroup
@@ -281,6 +287,34 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
     }
     if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
     return 0;
+}
+
+int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                          const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
+                          float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
+                          const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
+    return bf16_pass(3, dims, x, params, cond, eps_in, seed, offset, rng_state, eps_out, z_out, x_hat, mu, logvar, beta,
+                     grad_loss, grads, loss3, scratch, stream);
+}
+
+// The two halves as separate calls (validation runs only the first).  The forward leaves the bf16 activations, the MSE
+// gradient (already times *grad_loss) and the loss partial sums in `scratch`; the backward call must get the same
+// scratch, x, params, cond, eps_out, mu, logvar untouched.  The Philox state advances in the backward call.
+int psvae_forward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                       const float* eps_in, uint64_t seed, uint64_t offset, const uint64_t* rng_state, float* eps_out,
+                       float* z_out, float* x_hat, float* mu, float* logvar, const float* grad_loss, void* scratch,
+                       void* stream) {
+    return bf16_pass(1, dims, x, params, cond, eps_in, seed, offset, const_cast<uint64_t*>(rng_state), eps_out, z_out, x_hat,
+                     mu, logvar, 1.0f, grad_loss, nullptr, nullptr, scratch, stream);
+}
+
+int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
+                        uint64_t* rng_state, float* eps_out, float* z_out, float* x_hat, float* mu, float* logvar,
+                        float beta, const float* grad_loss, const psvae_grads* grads, float* loss3, void* scratch,
+                        void* stream) {
+    // eps_in = eps_out marks "epsilon was given": the backward never draws; rng_state (nullable) is advanced
+    return bf16_pass(2, dims, x, params, cond, nullptr, 0, 0, rng_state, eps_out, z_out, x_hat, mu, logvar, beta, grad_loss,
+                     grads, loss3, scratch, stream);
 }
 
 // ---- decode-only sampling in bf16 (VAEModel.decode, model.py:65-69; SURVEY 8b psvae_decode_bf16) ----------------

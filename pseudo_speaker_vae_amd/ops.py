@@ -228,6 +228,29 @@ def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: i
     return xh
 
 
+def forward_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], eps: Optional[torch.Tensor] = None, seed: int = 0,
+                 offset: int = 0, rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
+                 cond=None):
+    """forward half of the bf16 pass (psvae_forward_bf16): fills ws.x_hat / mu / logvar / eps / z and the scratch"""
+    P = _ffi.make_params(params)
+    _ffi.check(_ffi.lib().psvae_forward_bf16(
+        C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None, _ffi.ptr(eps),
+        seed, offset, _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat), _ffi.ptr(ws.mu),
+        _ffi.ptr(ws.logvar), _ffi.ptr(grad_loss), _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "forward_bf16")
+
+
+def backward_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], loss3,
+                  beta: float = 1.0, rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
+                  cond=None):
+    """backward half (psvae_backward_bf16) on the workspace a forward_bf16 call just filled"""
+    P = _ffi.make_params(params)
+    G = _ffi.make_grads(grads)
+    _ffi.check(_ffi.lib().psvae_backward_bf16(
+        C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None,
+        _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat), _ffi.ptr(ws.mu), _ffi.ptr(ws.logvar),
+        beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "backward_bf16")
+
+
 def decode_bf16(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
                 out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """VAEModel.decode with bf16 operands / fp32 accumulation (psvae_decode_bf16): the fast sampling mode"""

@@ -108,3 +108,41 @@ def test_bf16_decode_matches_emulation(D, Z, N, normalize):
     assert_close(got.cpu(), ref, BF16_TOL, "x_hat vs bf16 emulation")
     full = ops.decode(z.to(DEV), dec, D, flags=flags)
     assert rel_err(got.cpu(), full.cpu()) <= 3e-2, "bf16 decode vs fp32 decode"
+
+
+@pytest.mark.parametrize("B,cond", [(4096, True), (200, False)])
+def test_bf16_forward_plus_backward_equals_train_step(B, cond):
+    """psvae_forward_bf16 followed by psvae_backward_bf16 on the same workspace gives bitwise what
+    psvae_train_step_bf16 gives (outputs, loss, every gradient), and the forward alone leaves no gradient touched"""
+    from pseudo_speaker_vae_amd import _ffi, ops
+    D, Z = 256, 64
+    p = O.init_params(D, Z, 4)
+    torch.manual_seed(B)
+    x, eps = torch.randn(B, D).to(DEV), torch.randn(B, Z).to(DEV)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    keep, c1, c2 = [], None, None
+    if cond:
+        tabd = [(torch.randn(O.COND_DIM, O.HIDDEN) * 0.05).to(DEV) for _ in O.COND_KEYS]
+        gd, ad = torch.randint(-1, 3, (B,), dtype=torch.int32).to(DEV), torch.randint(-1, 3, (B,), dtype=torch.int32).to(DEV)
+        gt1 = [torch.full_like(t, float("nan")) for t in tabd]
+        gt2 = [torch.full_like(t, float("nan")) for t in tabd]
+        c1, c2 = _ffi.make_cond(tabd, gt1, gd, ad), _ffi.make_cond(tabd, gt2, gd, ad)
+        keep = [tabd, gd, ad, gt1, gt2]
+    go = torch.tensor([0.8], device=DEV)
+    ws1, ws2 = ops.Bf16Workspace(B, D, Z, DEV), ops.Bf16Workspace(B, D, Z, DEV)
+    g1 = [torch.full_like(t, float("nan")) for t in params]
+    g2 = [torch.full_like(t, float("nan")) for t in params]
+    l1, l2 = torch.full((3,), float("nan"), device=DEV), torch.full((3,), float("nan"), device=DEV)
+    ops.train_step_bf16(ws1, x, params, g1, l1, beta=0.6, eps=eps, grad_loss=go, cond=c1)
+    ops.forward_bf16(ws2, x, params, eps=eps, grad_loss=go, cond=c2)
+    torch.cuda.synchronize()
+    assert torch.equal(ws1.x_hat, ws2.x_hat) and torch.equal(ws1.mu, ws2.mu) and torch.equal(ws1.logvar, ws2.logvar)
+    assert all(torch.isnan(g).all() for g in g2) and torch.isnan(l2).all()
+    ops.backward_bf16(ws2, x, params, g2, l2, beta=0.6, grad_loss=go, cond=c2)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    if cond:
+        for a, b in zip(keep[3], keep[4]):
+            assert torch.equal(a, b)
