@@ -224,6 +224,23 @@ int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, con
                             const float* b2 /* hidden > 0 */, float grad_scale, float* loss2, float* g_z, float* gW1,
                             float* gb1, float* gW2, float* gb2, void* scratch, void* stream);
 
+/* EmbeddingClassifier consistency term on reconstructed embeddings (SURVEY N4;
+ * embedding_classifier/embedding_classifier.py:28-31,49-62 as used at lightning.py:44-52,100-108):
+ * logits = fc3 relu(fc2 relu(fc1 x_hat)), fc1 [hidden, D], fc2 [hidden, hidden], fc3 [C, hidden];
+ * loss2 = {mean cross entropy against y, number of rows whose argmax equals the label};
+ * g_xhat[B,D] = d(mean CE)/d(x_hat) * grad_scale (overwritten).  The head is frozen inside the VAE's training step
+ * (lightning.py:48-50): pass pg = NULL.  With pg the six parameter gradients {gW1, gb1, gW2, gb2, gW3, gb3} are
+ * written too (training the head itself, embedding_classifier.py:64-82).  hidden in {16, 32, 64, 128}, C <= 8,
+ * D % 4 == 0, labels in [0, C).  4 launches: fc1 GEMM, per-row kernel, loss reduction, one grouped GEMM. */
+typedef struct psvae_mlp3_grads {
+    float* g[6];
+} psvae_mlp3_grads;
+size_t psvae_consistency_scratch_bytes(int64_t B, int64_t hidden, int64_t C);
+int psvae_consistency_ce_f32(int64_t B, int64_t D, int64_t hidden, int64_t C, const float* x_hat, const int64_t* y,
+                             const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                             const float* b3, float grad_scale, float* loss2, float* g_xhat,
+                             const psvae_mlp3_grads* pg /* nullable */, void* scratch, void* stream);
+
 /* Batch assembly from a packed embedding table resident in HBM: out[b,:] = table[idx[b],:] (an
  * out-of-range index gives a zero row).  Stands in for the per-sample torch.load of
  * ps_vae/data/cv.py:58-76 / vctk.py:51-67 (one tiny file per embedding). */

@@ -425,6 +425,31 @@ def train_step_with_classifier(p, layers, x, y, eps, beta: float = 1.0, cw: floa
             [(cw * gW, cw * gb) for gW, gb in cgrads])
 
 
+def train_step_with_heads(p, layers, cons_layers, x, y, eps, beta: float = 1.0, cw: float = 1.0, sw: float = 1.0):
+    """lightning.py:67-131 with BOTH heads: a LatentClassifier on mu (lightning.py:73-98) and a frozen
+    EmbeddingClassifier (embedding_classifier.py:28-31,49-62: Linear-ReLU-Linear-ReLU-Linear) on x_hat
+    (lightning.py:100-108): total = recon + beta*kl + cw*CE(classifier(mu), y) + sw*CE(consistency(x_hat), y).
+    `layers` may be None (no latent head).  Returns dict(total, recon, kl, ce, hits, cons, cons_hits), the 18 VAE
+    gradients and [(dW, db), ...] of the latent classifier (the consistency head gets no gradient: frozen)."""
+    acts = forward(p, x, eps, False)
+    recon, kl, total = elbo(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False)
+    g_xh, g_mu, g_lv = elbo_grads(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False, 1.0)
+    out = dict(recon=recon, kl=kl)
+    cgrads = []
+    if layers is not None:
+        ce, hits, g_mu_cls, cg = classifier_ce(layers, acts["mu"], y)
+        g_mu = g_mu + cw * g_mu_cls
+        total = total + cw * ce
+        cgrads = [(cw * gW, cw * gb) for gW, gb in cg]
+        out.update(ce=ce, hits=hits)
+    cons, cons_hits, g_xh_cons, _ = classifier_ce(cons_layers, acts["x_hat"], y)
+    g_xh = g_xh + sw * g_xh_cons
+    total = total + sw * cons
+    out.update(total=total, cons=cons, cons_hits=cons_hits)
+    grads, _ = backward(p, x, acts, g_xh, g_mu, g_lv, False)
+    return out, grads, cgrads
+
+
 def langevin(layers, z0, noises, target: int, step_size: float, noise_weight: float):
     """inference.py:77-101 for a multiclass single-label classifier, closed-form gradient:
     grad = d/dz [log_softmax(logits)[target] - 0.5 |z|^2];  z += 0.5 s^2 grad + s w noise."""

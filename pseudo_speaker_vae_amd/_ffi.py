@@ -28,7 +28,7 @@ SYMBOLS = (
     "psvae_version", "psvae_debug_force_tile", "psvae_debug_force_wgrad_split", "psvae_strerror", "psvae_scratch_bytes", "psvae_philox_normal_f32",
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
     "psvae_tune_train_step_f32", "psvae_describe_plan", "psvae_set_plan",
-    "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
+    "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_consistency_scratch_bytes", "psvae_consistency_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
 )
@@ -48,6 +48,10 @@ class Grads(C.Structure):
 
 class Cond(C.Structure):
     _fields_ = [("tab", C.c_void_p * 3), ("gtab", C.c_void_p * 3), ("gender", C.c_void_p), ("age", C.c_void_p)]
+
+
+class Mlp3Grads(C.Structure):
+    _fields_ = [("g", C.c_void_p * 6)]
 
 
 ACT_FIELDS = ("h1m", "h2m", "h1s", "h2s", "eps", "z", "d1", "d2", "ynorm")
@@ -110,6 +114,11 @@ def lib() -> C.CDLL:
     L.psvae_classifier_scratch_bytes.restype = C.c_size_t
     L.psvae_classifier_ce_f32.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.psvae_classifier_ce_f32.restype = C.c_int
+    L.psvae_consistency_scratch_bytes.argtypes = [i64, i64, i64]
+    L.psvae_consistency_scratch_bytes.restype = C.c_size_t
+    L.psvae_consistency_ce_f32.argtypes = [i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp,
+                                           C.POINTER(Mlp3Grads), vp, vp]
+    L.psvae_consistency_ce_f32.restype = C.c_int
     L.psvae_decode_bf16_scratch_bytes.argtypes = [i64, i64, i64]
     L.psvae_decode_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_decode_bf16.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, u32, vp]

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void classifier_ce_kernel(int64_t B, int hidde
                                                             const float* __restrict__ b2, float scale,
                                                             float* __restrict__ h_out, float* __restrict__ dh_out,
                                                             float* __restrict__ dlogits, float* __restrict__ g_z,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, int relu_input) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[8];
     const int rows1 = hidden > 0 ? hidden : C;
@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void classifier_ce_kernel(int64_t B, int hidde
                 for (int k = 0; k < ZD; ++k) gz[k] = fmaf(sW1[c * ZD + k], gl[c], gz[k]);
             }
     }
+    if (relu_input) {  // z is the output of a ReLU (EmbeddingClassifier fc1): hand back the gradient of its pre-activation
+#pragma unroll
+        for (int k = 0; k < ZD; ++k) gz[k] = z[k] > 0.f ? gz[k] : 0.f;
+    }
     if (live) {
 #pragma unroll
         for (int k = 0; k < ZD; k += 4)
@@ -171,7 +175,8 @@ int classifier_blocks(int64_t B) { return (int)((B + 255) / 256); }
 
 hipError_t launch_classifier_ce(int64_t B, int Z, int hidden, int C, const float* z, const int64_t* y, const float* W1,
                                 const float* b1, const float* W2, const float* b2, float scale, float* h_out,
-                                float* dh_out, float* dlogits, float* g_z, float* partials, float* loss2, hipStream_t s) {
+                                float* dh_out, float* dlogits, float* g_z, float* partials, float* loss2, hipStream_t s,
+                                int relu_input) {
     const int rows1 = hidden > 0 ? hidden : C;
     const size_t lds = (size_t)(rows1 * Z + ((rows1 + 3) & ~3) + C * hidden + 8) * sizeof(float);
     const int grid = classifier_blocks(B);
@@ -179,12 +184,14 @@ hipError_t launch_classifier_ce(int64_t B, int Z, int hidden, int C, const float
     case ZD: {                                                                                                        \
         static bool done = false;                                                                                     \
         if (!done && lds > 48 * 1024) {                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&classifier_ce_kernel<ZD>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            /* (the kernel also has 32 B of static LDS: the dynamic limit must leave room for it) */                  \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&classifier_ce_kernel<ZD>),             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);              \
+            if (ea != hipSuccess) return ea;                                                                          \
             done = true;                                                                                              \
         }                                                                                                             \
         hipLaunchKernelGGL(classifier_ce_kernel<ZD>, dim3(grid), dim3(256), lds, s, B, hidden, C, z, y, W1, b1, W2, b2, \
-                           scale, h_out, dh_out, dlogits, g_z, partials);                                             \
+                           scale, h_out, dh_out, dlogits, g_z, partials, relu_input);                                           \
         break;                                                                                                        \
     }
     switch (Z) {

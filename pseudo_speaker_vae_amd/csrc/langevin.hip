@@ -184,8 +184,9 @@ hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1,
     case ZD: {                                                                                                         \
         static bool done = false;                                                                                      \
         if (!done && lds > 48 * 1024) {                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&langevin_kernel<ZD>),                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&langevin_kernel<ZD>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+            if (ea != hipSuccess) return ea;                                                                           \
             done = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL(langevin_kernel<ZD>, dim3(grid), dim3(256), lds, s, N, hidden, C, W1, b1, W2, b2, z, target, \

@@ -796,6 +796,55 @@ int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, con
     return 0;
 }
 
+// scratch of psvae_consistency_ce_f32: a1 | g_pre1 | the classifier step's own scratch
+size_t psvae_consistency_scratch_bytes(int64_t B, int64_t hidden, int64_t C) {
+    if (B <= 0 || C <= 0 || hidden <= 0) return 0;
+    return 2 * align_up((size_t)B * hidden * sizeof(float), 256) + psvae_classifier_scratch_bytes(B, hidden, C);
+}
+
+int psvae_consistency_ce_f32(int64_t B, int64_t D, int64_t hidden, int64_t C, const float* x_hat, const int64_t* y,
+                             const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                             const float* b3, float grad_scale, float* loss2, float* g_xhat, const psvae_mlp3_grads* pg,
+                             void* scratch, void* stream) {
+    if (!x_hat || !y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !loss2 || !g_xhat || !scratch) return PSVAE_ERR_NULL;
+    if (pg)
+        for (int i = 0; i < 6; ++i)
+            if (!pg->g[i]) return PSVAE_ERR_NULL;
+    if (B <= 0 || D <= 0 || (D & 3) || C <= 0 || C > 8) return PSVAE_ERR_SHAPE;
+    if (!(hidden == 16 || hidden == 32 || hidden == 64 || hidden == 128)) return PSVAE_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x_hat) & 15) || (reinterpret_cast<uintptr_t>(g_xhat) & 15)) return PSVAE_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int Bi = (int)B, Di = (int)D, Hi = (int)hidden, Ci = (int)C;
+    char* base = reinterpret_cast<char*>(scratch);
+    const size_t hb = align_up((size_t)B * hidden * sizeof(float), 256);
+    float* a1 = reinterpret_cast<float*>(base);        // relu(fc1(x_hat))                     [B, hidden]
+    float* gp1 = reinterpret_cast<float*>(base + hb);  // d loss / d (fc1 pre-activation)      [B, hidden]
+    char* cb = base + 2 * hb;                          // classifier step scratch: h | dh | dlogits | partials
+    float* h = reinterpret_cast<float*>(cb);
+    float* dh = reinterpret_cast<float*>(cb + hb);
+    float* dl = reinterpret_cast<float*>(cb + 2 * hb);
+    float* partials = reinterpret_cast<float*>(cb + 2 * hb + align_up((size_t)B * C * sizeof(float), 256));
+    {  // fc1 + ReLU (embedding_classifier.py:60)
+        GemmBatch b{};
+        add(b, make_desc(GK_NT, Bi, Hi, Di, x_hat, Di, W1, Di, a1, Hi, EPI_BIAS_RELU, b1));
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    // fc2 + ReLU + fc3 + cross entropy and everything back to fc1's pre-activation, one lane per row (:61-62, lightning.py:101-102)
+    RET_IF(launch_classifier_ce(B, Hi, Hi, Ci, a1, y, W2, b2, W3, b3, grad_scale / (float)B, h, dh, dl, gp1, partials, loss2,
+                                s, /*relu_input=*/1));
+    {  // g_xhat = g_pre1 W1; with pg also the three weight gradients (bias gradients = column sums), one launch
+        GemmBatch b{};
+        add(b, make_desc(GK_NN, Bi, Di, Hi, gp1, Hi, W1, Di, g_xhat, Di, EPI_NONE, nullptr));
+        if (pg) {
+            add(b, make_desc(GK_TN, Hi, Di, Bi, gp1, Hi, x_hat, Di, pg->g[0], Di, EPI_NONE, nullptr, pg->g[1]));
+            add(b, make_desc(GK_TN, Hi, Hi, Bi, dh, Hi, a1, Hi, pg->g[2], Hi, EPI_NONE, nullptr, pg->g[3]));
+            add(b, make_desc(GK_TN, Ci, Hi, Bi, dl, Ci, h, Hi, pg->g[4], Hi, EPI_NONE, nullptr, pg->g[5]));
+        }
+        RET_IF(launch_gemm_batch(b, 0, s));
+    }
+    return 0;
+}
+
 int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_t* idx, int64_t B, float* out,
                           void* stream) {
     if (!table || !idx || !out) return PSVAE_ERR_NULL;

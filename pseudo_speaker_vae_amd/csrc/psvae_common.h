@@ -197,7 +197,8 @@ hipError_t launch_transpose_f32(const float* const* src, float* const* dst, cons
 int classifier_blocks(int64_t B);
 hipError_t launch_classifier_ce(int64_t B, int Z, int hidden, int C, const float* z, const int64_t* y, const float* W1,
                                 const float* b1, const float* W2, const float* b2, float scale, float* h_out,
-                                float* dh_out, float* dlogits, float* g_z, float* partials, float* loss2, hipStream_t s);
+                                float* dh_out, float* dlogits, float* g_z, float* partials, float* loss2, hipStream_t s,
+                                int relu_input = 0);
 hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1, const float* b1, const float* W2,
                            const float* b2, float* z, int target, float step_size, float noise_weight,
                            int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,

@@ -8,8 +8,11 @@ has no Lightning (and no network), so a minimal stand-in base supplies what the 
 use: save_hyperparameters / hparams / log / device / load_from_checkpoint.
 
 training_step / validation_step with no classifier branches run forward + ELBO as ONE fused autograd
-Function on the GPU (model.ELBOStepFunction); with a classifier or consistency head the VAE still runs
-through the HIP forward/backward (model.VAEForwardFunction) and the small heads use torch ops.
+Function on the GPU (model.ELBOStepFunction); so does the single-label LatentClassifier head
+(model.ELBOClassifierStepFunction).  With a consistency head (EmbeddingClassifier on x_hat) the VAE runs through the
+HIP forward/backward (model.VAEForwardFunction) and each head is its own fused HIP autograd node
+(latent_classifier._ClassifierCEFunction, embedding_classifier._ConsistencyCEFunction); only head shapes those
+kernels do not cover (multi-label, other activations, hidden > 128) fall to torch ops.
 """
 from __future__ import annotations
 
@@ -45,9 +48,14 @@ except Exception:  # ModuleNotFoundError here
             self.logged: Dict[str, Any] = {}
 
         def save_hyperparameters(self):
+            # Lightning semantics: the caller's __init__ arguments, a **kwargs dict merged in flat
             frame = inspect.currentframe().f_back
-            loc = frame.f_locals
-            hp = dict(loc.get("hparams", {}))
+            code, loc = frame.f_code, frame.f_locals
+            nargs = code.co_argcount + code.co_kwonlyargcount
+            hp = {n: loc[n] for n in code.co_varnames[1:nargs] if n in loc}
+            if code.co_flags & inspect.CO_VARKEYWORDS:
+                kwname = code.co_varnames[nargs + (1 if code.co_flags & inspect.CO_VARARGS else 0)]
+                hp.update(loc.get(kwname, {}))
             self._hparams = _HParams(hp)
 
         @property
@@ -116,10 +124,13 @@ class PseudoSpeakerVAE(_Base):
             self.classifier = None
 
         if "consistency_classifier_ckpt" in hparams:                       # lightning.py:44-52
-            raise NotImplementedError(
-                "consistency_classifier_ckpt: the EmbeddingClassifier consistency head is out of the hot-path scope "
-                "(SURVEY.md section 2 C5); train without it")
-        self.consistency_classifier = None
+            from .embedding_classifier import EmbeddingClassifier  # (it derives from _Base above)
+            self.consistency_classifier = EmbeddingClassifier.load_from_checkpoint(hparams["consistency_classifier_ckpt"])
+            for param in self.consistency_classifier.parameters():
+                param.requires_grad = False
+            self.consistency_classifier.eval()
+        else:
+            self.consistency_classifier = None
 
         self.kl_loss_weight = hparams.get("kl_loss_weight", 1.0)           # lightning.py:54-57
         self.classifier_loss_weight = hparams.get("classifier_loss_weight", 1.0)
@@ -137,10 +148,11 @@ class PseudoSpeakerVAE(_Base):
         x, y = batch
         log_kw = dict(sync_dist=True) if prefix == "train" else dict(batch_size=x.size(0), sync_dist=True)
         vae_trainable = any(p.requires_grad for p in self.model.parameters())
-        if self.classifier is None and (vae_trainable or not torch.is_grad_enabled()):
+        cons = self.consistency_classifier
+        if cons is None and self.classifier is None and (vae_trainable or not torch.is_grad_enabled()):
             # fused: forward + ELBO on the GPU, one autograd node (lightning.py:110-124)
             total, recon, kl, _, _, _ = self.model.elbo_step(x, self.kl_loss_weight, self.use_cos_loss)
-        elif (self.classifier is not None and not self.multilabel and x.is_cuda and not isinstance(y, dict)
+        elif (cons is None and self.classifier is not None and not self.multilabel and x.is_cuda and not isinstance(y, dict)
               and self.classifier.fused_params() is not None and (vae_trainable or not torch.is_grad_enabled())):
             # fused: forward + ELBO + classifier cross entropy + (when training) the whole backward, one autograd node
             total, recon, kl, ce, hits, _, _, _ = self.model.elbo_classifier_step(
@@ -172,12 +184,26 @@ class PseudoSpeakerVAE(_Base):
                         self.log(f"{prefix}_classifier_acc_{name}", self.accuracy[name](y_hat[name], y[name]), sync_dist=True)
                         self.log(f"{prefix}_classifier_loss_{name}", classifier_loss, sync_dist=True)
                     classifier_loss = classifier_loss / len(y_hat)
+            consistency_loss = 0
+            if cons is not None:                                           # lightning.py:100-108
+                # the reference takes the accuracy from self.accuracy, which only exists with a latent classifier
+                # configured (lightning.py:33 vs 103); here it comes from the head's own step and needs neither
+                if x_hat.is_cuda and cons.fused_ok() and not isinstance(y, dict):
+                    consistency_loss, hits = cons.cross_entropy_step(x_hat, y)   # fused HIP step, 4 launches
+                    consistency_acc = hits / x.size(0)
+                else:
+                    y_hat_consistency = cons(x_hat)
+                    consistency_loss = nn.functional.cross_entropy(y_hat_consistency, y)
+                    consistency_acc = (y_hat_consistency.argmax(-1) == y).float().mean()
+                self.log(f"{prefix}_consistency", consistency_acc, sync_dist=True)
+                self.log(f"{prefix}_consistency_loss", consistency_loss, sync_dist=True)
             if self.use_cos_loss:                                          # lightning.py:110-113
                 recon = nn.functional.cosine_embedding_loss(x_hat, x, torch.ones(x.size(0), device=x.device))
             else:
                 recon = nn.functional.mse_loss(x_hat, x, reduction="mean") / 10
             kl = -0.5 * torch.mean(torch.sum(1 + log_sigma - mu.pow(2) - log_sigma.exp(), dim=-1))
-            total = recon + self.kl_loss_weight * kl + self.classifier_loss_weight * classifier_loss
+            total = (recon + self.kl_loss_weight * kl + self.classifier_loss_weight * classifier_loss
+                     + self.consitency_loss_weight * consistency_loss)                  # lightning.py:119-124
         self.log(f"{prefix}_loss", total, **log_kw)                        # lightning.py:127-129 / 193-195
         self.log(f"{prefix}_recon_loss", recon, **log_kw)
         self.log(f"{prefix}_kl_loss", kl, **log_kw)

@@ -203,6 +203,76 @@ def make_classifier_step_case(name, D, Z, B, num_layers, hidden, cw, beta=1.0):
     print(f"{name}: total={fx['total']:.6f} ce={fx['ce']:.6f} acc={fx['acc']:.4f}")
 
 
+def make_consistency_step_case(name, D, Z, B, hidden, cw, sw, beta=1.0):
+    """the reference's training_step with a LatentClassifier head AND a frozen EmbeddingClassifier consistency head
+    (lightning.py:44-52,100-108).  The reference builds the head with load_from_checkpoint (a Lightning feature the
+    stand-in base does not have), so it is constructed here from the reference's class and attached, frozen and in
+    eval mode, exactly as lightning.py:48-50 leaves it.  (self.accuracy only exists with a classifier configured,
+    lightning.py:33 vs 103 -- hence both heads.)"""
+    from ps_vae.embedding_classifier.embedding_classifier import EmbeddingClassifier
+    assert os.path.realpath(sys.modules[EmbeddingClassifier.__module__].__file__).startswith(REF)
+    torch.manual_seed(5)
+    hp = dict(model=dict(input_dim=D, latent_dim=Z, normalize_decoder=False), kl_loss_weight=beta,
+              classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=128, activation="relu"),
+              classifier_loss_weight=cw, consistency_loss_weight=sw)
+    mod = PseudoSpeakerVAE(**hp)
+    torch.manual_seed(9)
+    cons = EmbeddingClassifier(input_dim=D, num_classes=3, hidden_dim=hidden)
+    with torch.no_grad():
+        for q in list(mod.classifier.parameters()) + list(cons.parameters()):
+            q.mul_(3.0)  # default init gives near-uniform logits
+    for q in cons.parameters():
+        q.requires_grad = False
+    cons.eval()
+    mod.consistency_classifier = cons
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, D, generator=g)
+    y = torch.randint(0, 3, (B,), generator=g)
+    torch.manual_seed(2100)
+    out = mod.training_step((x, y), 0)
+    torch.manual_seed(2100)
+    eps = torch.randn(B, Z)
+    out["loss"].backward()
+    fx = dict(D=D, Z=Z, B=B, pseed=5, beta=beta, cw=cw, sw=sw, hidden=hidden, x=x.numpy(), y=y.numpy(), eps=eps.numpy(),
+              total=np.float64(out["loss"].item()), recon=np.float64(mod._logged["train_recon_loss"]),
+              kl=np.float64(mod._logged["train_kl_loss"]), ce=np.float64(mod._logged["train_classifier_loss"]),
+              acc=np.float64(mod._logged["train_classifier_acc"]),
+              cons=np.float64(mod._logged["train_consistency_loss"]),
+              cons_acc=np.float64(mod._logged["train_consistency"]))
+    lins = [l for l in mod.classifier.layers if isinstance(l, nn.Linear)]
+    for i, l in enumerate(lins):
+        fx[f"cls_w{i}"] = l.weight.detach().numpy()
+        fx[f"cls_b{i}"] = l.bias.detach().numpy()
+        fx[f"cls_gw{i}"] = l.weight.grad.numpy().copy()
+        fx[f"cls_gb{i}"] = l.bias.grad.numpy().copy()
+    for i, l in enumerate((cons.fc1, cons.fc2, cons.fc3)):
+        fx[f"cons_w{i}"] = l.weight.detach().numpy()
+        fx[f"cons_b{i}"] = l.bias.detach().numpy()
+    # the head alone on a given input: logits + d CE / d input and its own parameter gradients (training the head)
+    cons2 = EmbeddingClassifier(input_dim=D, num_classes=3, hidden_dim=hidden)
+    cons2.load_state_dict(cons.state_dict())
+    xin = (x * 0.5).clone().requires_grad_()
+    logits = cons2(xin)
+    l2 = cons2.loss_fn(logits, y)
+    l2.backward()
+    fx.update(head_x=xin.detach().numpy(), head_logits=logits.detach().numpy(), head_loss=np.float64(l2.item()),
+              head_gx=xin.grad.numpy().copy())
+    for i, l in enumerate((cons2.fc1, cons2.fc2, cons2.fc3)):
+        fx[f"head_gw{i}"] = l.weight.grad.numpy().copy()
+        fx[f"head_gb{i}"] = l.bias.grad.numpy().copy()
+    for i, k in enumerate(O.PARAM_KEYS):
+        gr = dict(mod.model.named_parameters())[k].grad
+        fx[f"gck/{k}"] = checksum(gr)
+        if gr.dim() == 1:
+            fx[f"g/{k}"] = gr.numpy().copy()
+        else:
+            idx = sample_idx(gr.numel(), 7 + i)
+            fx[f"gi/{k}"] = idx
+            fx[f"g/{k}"] = gr.reshape(-1)[idx].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"{name}: total={fx['total']:.6f} ce={fx['ce']:.6f} cons={fx['cons']:.6f} cons_acc={fx['cons_acc']:.4f}")
+
+
 def make_decode_case(name, D, Z, N, pseed, normalize):
     torch.manual_seed(pseed)
     m = VAEModel(D, Z, normalize)
@@ -271,6 +341,10 @@ def make_label_maps(name):
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "consistency":  # only the newest family (the rest is unchanged)
+        make_consistency_step_case("consstep_d256_z64_b21_h128", 256, 64, 21, 128, 0.3, 0.7)
+        make_consistency_step_case("consstep_d512_z128_b9_h64", 512, 128, 9, 64, 1.0, 1.0, beta=0.5)
+        sys.exit(0)
     # cfg1 shape (D=256,Z=32), cfg2 shape (256,64), cfg4 shape (512,128); small batches incl. ragged ones
     make_step_case("step_d256_z32_b8_s0", 256, 32, 8, 0, 0)
     make_step_case("step_d256_z64_b16_s0", 256, 64, 16, 0, 0)
@@ -290,3 +364,5 @@ if __name__ == "__main__":
     make_label_maps("label_maps")
     make_classifier_step_case("clfstep_d256_z64_b24_h128", 256, 64, 24, 2, 128, 0.3)
     make_classifier_step_case("clfstep_d256_z64_b19_lin", 256, 64, 19, 1, 128, 1.0, beta=0.5)
+    make_consistency_step_case("consstep_d256_z64_b21_h128", 256, 64, 21, 128, 0.3, 0.7)
+    make_consistency_step_case("consstep_d512_z128_b9_h64", 512, 128, 9, 64, 1.0, 1.0, beta=0.5)

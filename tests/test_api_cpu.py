@@ -85,6 +85,34 @@ def test_checkpoint_round_trip_and_partial_vae_load(tmp_path):
     assert not any(p.requires_grad for p in c.model.parameters())
 
 
+def test_embedding_classifier_surface_and_consistency_checkpoint(tmp_path):
+    """EmbeddingClassifier (embedding_classifier.py:6-62): constructor, state_dict keys, hparams, optimizer; loaded frozen
+    by PseudoSpeakerVAE from a Lightning-layout checkpoint (lightning.py:44-52); no CPU path for the fused step"""
+    from ps_vae.embedding_classifier.embedding_classifier import EmbeddingClassifier
+    from ps_vae.lightning import PseudoSpeakerVAE
+    from pseudo_speaker_vae_amd._ffi import PsvaeError
+    torch.manual_seed(3)
+    head = EmbeddingClassifier(input_dim=64, num_classes=3, hidden_dim=32, optimizer_cfg=dict(lr=1e-2))
+    assert [k for k in head.state_dict()] == ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"]
+    assert head.fc1.weight.shape == (32, 64) and head.fc2.weight.shape == (32, 32) and head.fc3.weight.shape == (3, 32)
+    assert dict(head.hparams) == dict(input_dim=64, num_classes=3, hidden_dim=32, optimizer_cfg=dict(lr=1e-2))
+    opt = head.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 1e-2
+    assert head(torch.randn(5, 64)).shape == (5, 3)               # plain forward (logits) works anywhere
+    with pytest.raises(PsvaeError):
+        head.cross_entropy_step(torch.randn(5, 64), torch.zeros(5, dtype=torch.int64))
+    path = os.path.join(tmp_path, "head.ckpt")
+    head.save_checkpoint(path)
+    m = PseudoSpeakerVAE(model=dict(input_dim=64, latent_dim=16), consistency_classifier_ckpt=path,
+                         consistency_loss_weight=0.25)
+    c = m.consistency_classifier
+    assert isinstance(c, EmbeddingClassifier) and not c.training and m.consitency_loss_weight == 0.25
+    assert not any(q.requires_grad for q in c.parameters())
+    for k, v in head.state_dict().items():
+        assert torch.equal(c.state_dict()[k], v)
+    assert any(k.startswith("consistency_classifier.fc1") for k in m.state_dict())
+
+
 def test_label_maps_match_reference_fixture():
     from ps_vae.utils import METADATA_TRANSFORMS, map_cv_age_to_label, map_cv_gender_to_label, map_vctk_gender_to_label
     fx = load(os.path.join(GOLDEN, "label_maps.npz"))

@@ -337,7 +337,8 @@ def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
     assert torch.isfinite(total) and all(t.grad is None for t in m.ordered_params())
 
 
-@pytest.mark.parametrize("Z,hidden,C,B", [(64, 128, 3, 300), (64, 0, 3, 1000), (32, 64, 8, 257), (128, 16, 2, 64), (16, 0, 5, 33)])
+@pytest.mark.parametrize("Z,hidden,C,B", [(64, 128, 3, 300), (64, 0, 3, 1000), (32, 64, 8, 257), (128, 16, 2, 64), (16, 0, 5, 33),
+                                          (128, 128, 8, 130)])  # the last one needs > 64 KB of LDS
 def test_classifier_cross_entropy_step_matches_oracle(Z, hidden, C, B):
     """psvae_classifier_ce_f32 behind LatentClassifier.cross_entropy_step: loss, hit count, d/dz and every parameter
     gradient against torch-CPU autograd (oracle.classifier_ce), with an upstream scale applied in backward."""
@@ -462,3 +463,131 @@ def test_validation_step_runs_without_grad_on_both_fused_paths():
         mod.model._philox_offset = 0
         tr = mod.training_step((x, y), 0)
         assert abs(float(tr["loss"]) - float(out["loss"])) <= 1e-6 * max(1.0, abs(float(out["loss"])))
+
+
+@pytest.mark.parametrize("D,hidden,C,B,train_head", [(256, 128, 3, 300, True), (256, 128, 3, 1024, False),
+                                                     (512, 64, 8, 257, True), (64, 16, 2, 33, True),
+                                                     (260, 32, 5, 1, False)])
+def test_consistency_cross_entropy_step_matches_oracle(D, hidden, C, B, train_head):
+    """psvae_consistency_ce_f32 behind EmbeddingClassifier.cross_entropy_step: loss, hit count, d/d x_hat and (when the
+    head trains) its six parameter gradients against torch-CPU autograd (oracle.classifier_ce on the 3-layer head),
+    with an upstream scale applied in backward.  Frozen head: no parameter gradient appears."""
+    from pseudo_speaker_vae_amd.embedding_classifier import EmbeddingClassifier
+    torch.manual_seed(D + hidden + C)
+    head = EmbeddingClassifier(D, C, hidden).to(DEV)
+    with torch.no_grad():
+        for q in head.parameters():
+            q.mul_(2.0)
+    if not train_head:
+        for q in head.parameters():
+            q.requires_grad = False
+    x = torch.randn(B, D)
+    y = torch.randint(0, C, (B,))
+    xg = x.to(DEV).requires_grad_()
+    loss, hits = head.cross_entropy_step(xg, y.to(DEV))
+    (loss * 0.41).backward()
+    lins = (head.fc1, head.fc2, head.fc3)
+    layers = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in lins]
+    oloss, ohits, ogx, ograds = O.classifier_ce(layers, x, y)
+    assert abs(float(loss) - float(oloss)) <= REL_TOL * max(1.0, abs(float(oloss)))
+    assert int(hits) == ohits
+    assert_close(xg.grad.cpu(), 0.41 * ogx, REL_TOL, "d/dx_hat")
+    for l, (gW, gb) in zip(lins, ograds):
+        if train_head:
+            assert_close(l.weight.grad.cpu(), 0.41 * gW, REL_TOL, "dW")
+            assert_close(l.bias.grad.cpu(), 0.41 * gb, REL_TOL, "db")
+        else:
+            assert l.weight.grad is None and l.bias.grad is None
+    # logits of the module's own forward agree with the oracle too (the non-fused consumers of the head)
+    assert_close(head(x.to(DEV)).detach().cpu(), O.classifier_forward(layers, x), REL_TOL, "logits")
+
+
+def test_consistency_step_rejects_what_the_kernel_does_not_cover():
+    from pseudo_speaker_vae_amd import _ffi
+    from pseudo_speaker_vae_amd.embedding_classifier import EmbeddingClassifier
+    head = EmbeddingClassifier(256, 3, 100).to(DEV)  # hidden not in {16, 32, 64, 128}
+    assert not head.fused_ok()
+    with pytest.raises(_ffi.PsvaeError):
+        head.cross_entropy_step(torch.randn(4, 256, device=DEV), torch.zeros(4, dtype=torch.int64, device=DEV))
+    lib = _ffi.lib()
+    assert lib.psvae_consistency_scratch_bytes(0, 128, 3) == 0
+    t = torch.zeros(64, device=DEV)
+    args = [_ffi.ptr(t)] * 8
+    # bad hidden, bad C, D not a multiple of 4: refused before any launch
+    for (B, D, h, C) in ((4, 256, 100, 3), (4, 256, 128, 9), (4, 258, 128, 3)):
+        rc = lib.psvae_consistency_ce_f32(B, D, h, C, *args, 1.0, _ffi.ptr(t), _ffi.ptr(t), None, _ffi.ptr(t), None)
+        assert rc < 0
+
+
+@pytest.mark.parametrize("name", ["consstep_d256_z64_b21_h128", "consstep_d512_z128_b9_h64"])
+def test_training_step_with_consistency_head_matches_reference_golden(name, tmp_path):
+    """training_step with a LatentClassifier on mu and a frozen EmbeddingClassifier on x_hat, the head loaded from a
+    Lightning-layout checkpoint as lightning.py:44-52 does, against the fixture generated from the reference's own
+    training_step + backward: the four loss terms, both accuracies, all 18 VAE gradients, the classifier's; the
+    consistency head stays without gradients"""
+    from ps_vae.embedding_classifier.embedding_classifier import EmbeddingClassifier
+    from ps_vae.lightning import PseudoSpeakerVAE
+    from helpers import check_grads_against_fixture
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    D, Z, hidden = int(fx["D"]), int(fx["Z"]), int(fx["hidden"])
+    head = EmbeddingClassifier(input_dim=D, num_classes=3, hidden_dim=hidden)
+    with torch.no_grad():
+        for i, l in enumerate((head.fc1, head.fc2, head.fc3)):
+            l.weight.copy_(torch.from_numpy(fx[f"cons_w{i}"]))
+            l.bias.copy_(torch.from_numpy(fx[f"cons_b{i}"]))
+    ckpt = str(tmp_path / "head.ckpt")
+    head.save_checkpoint(ckpt)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), kl_loss_weight=float(fx["beta"]),
+                           classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=128, activation="relu"),
+                           classifier_loss_weight=float(fx["cw"]), consistency_loss_weight=float(fx["sw"]),
+                           consistency_classifier_ckpt=ckpt)
+    assert mod.consistency_classifier.hidden_dim == hidden and not mod.consistency_classifier.training
+    mod.model.load_state_dict(O.init_params(D, Z, int(fx["pseed"])))
+    lins = [l for l in mod.classifier.layers if isinstance(l, torch.nn.Linear)]
+    with torch.no_grad():
+        for i, l in enumerate(lins):
+            l.weight.copy_(torch.from_numpy(fx[f"cls_w{i}"]))
+            l.bias.copy_(torch.from_numpy(fx[f"cls_b{i}"]))
+    mod = mod.to(DEV)
+    eps = torch.from_numpy(fx["eps"]).to(DEV)
+    orig = mod.model.forward
+    mod.model.forward = lambda xx: orig(xx, eps=eps)
+    out = mod.training_step((torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["y"]).to(DEV)), 0)
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(fx["total"])) <= REL_TOL * max(1.0, abs(float(fx["total"])))
+    for key, ref in (("train_classifier_loss", "ce"), ("train_consistency_loss", "cons"), ("train_recon_loss", "recon"),
+                     ("train_kl_loss", "kl")):
+        assert abs(float(mod.logged[key]) - float(fx[ref])) <= REL_TOL * max(1.0, abs(float(fx[ref]))), key
+    assert abs(float(mod.logged["train_classifier_acc"]) - float(fx["acc"])) < 1e-6
+    assert abs(float(mod.logged["train_consistency"]) - float(fx["cons_acc"])) < 1e-6
+    check_grads_against_fixture({k: t.grad for k, t in zip(O.PARAM_KEYS, mod.model.ordered_params())}, fx)
+    for i, l in enumerate(lins):
+        assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"cls_gw{i}"]), REL_TOL, f"classifier dW{i}")
+        assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"cls_gb{i}"]), REL_TOL, f"classifier db{i}")
+    assert all(q.grad is None for q in mod.consistency_classifier.parameters())
+
+
+@pytest.mark.parametrize("name", ["consstep_d256_z64_b21_h128", "consstep_d512_z128_b9_h64"])
+def test_embedding_classifier_training_step_matches_reference_golden(name):
+    """EmbeddingClassifier.training_step (embedding_classifier.py:64-82) on the fused step against the reference head's
+    own loss and autograd gradients"""
+    from ps_vae.embedding_classifier.embedding_classifier import EmbeddingClassifier
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    head = EmbeddingClassifier(input_dim=int(fx["D"]), num_classes=3, hidden_dim=int(fx["hidden"]))
+    lins = (head.fc1, head.fc2, head.fc3)
+    with torch.no_grad():
+        for i, l in enumerate(lins):
+            l.weight.copy_(torch.from_numpy(fx[f"cons_w{i}"]))
+            l.bias.copy_(torch.from_numpy(fx[f"cons_b{i}"]))
+    head = head.to(DEV)
+    xin = torch.from_numpy(fx["head_x"]).to(DEV).requires_grad_()
+    loss = head.training_step((xin, torch.from_numpy(fx["y"]).to(DEV)), 0)
+    loss.backward()
+    assert abs(float(loss) - float(fx["head_loss"])) <= REL_TOL
+    assert abs(float(head.logged["train_loss"]) - float(fx["head_loss"])) <= REL_TOL
+    assert_close(xin.grad.cpu(), torch.from_numpy(fx["head_gx"]), REL_TOL, "d loss / d x")
+    for i, l in enumerate(lins):
+        assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"head_gw{i}"]), REL_TOL, f"dW{i}")
+        assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"head_gb{i}"]), REL_TOL, f"db{i}")
+    opt = head.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and len(opt.param_groups[0]["params"]) == 6

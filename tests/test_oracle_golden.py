@@ -158,3 +158,47 @@ def test_training_step_with_classifier_head_matches_reference(name):
     for i, (gW, gb) in enumerate(cgrads):
         assert_close(gW, torch.from_numpy(fx[f"cls_gw{i}"]), 2e-5, f"classifier dW{i}")
         assert_close(gb, torch.from_numpy(fx[f"cls_gb{i}"]), 2e-5, f"classifier db{i}")
+
+
+CONS_CASES = ["consstep_d256_z64_b21_h128", "consstep_d512_z128_b9_h64"]
+
+
+def cons_layers(fx, prefix="cons"):
+    return [(torch.from_numpy(fx[f"{prefix}_w{i}"]), torch.from_numpy(fx[f"{prefix}_b{i}"])) for i in range(3)]
+
+
+@pytest.mark.parametrize("name", CONS_CASES)
+def test_training_step_with_consistency_head_matches_reference(name):
+    """oracle.train_step_with_heads against the reference's own training_step + backward with a LatentClassifier on mu
+    AND a frozen EmbeddingClassifier on x_hat (lightning.py:44-52,100-108): the four loss terms, both accuracies, all
+    18 VAE gradients and the latent classifier's"""
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    layers = [(torch.from_numpy(fx[f"cls_w{i}"]), torch.from_numpy(fx[f"cls_b{i}"])) for i in range(2)]
+    x, y, eps = torch.from_numpy(fx["x"]), torch.from_numpy(fx["y"]), torch.from_numpy(fx["eps"])
+    losses, grads, cgrads = O.train_step_with_heads(p, layers, cons_layers(fx), x, y, eps, float(fx["beta"]),
+                                                    float(fx["cw"]), float(fx["sw"]))
+    for k in ("total", "recon", "kl", "ce", "cons"):
+        assert abs(float(losses[k]) - float(fx[k])) <= 2e-5 * max(1.0, abs(float(fx[k]))), k
+    assert abs(losses["hits"] / x.shape[0] - float(fx["acc"])) < 1e-6
+    assert abs(losses["cons_hits"] / x.shape[0] - float(fx["cons_acc"])) < 1e-6
+    check_grads_against_fixture(grads, fx, tol=2e-5)
+    for i, (gW, gb) in enumerate(cgrads):
+        assert_close(gW, torch.from_numpy(fx[f"cls_gw{i}"]), 2e-5, f"classifier dW{i}")
+        assert_close(gb, torch.from_numpy(fx[f"cls_gb{i}"]), 2e-5, f"classifier db{i}")
+
+
+@pytest.mark.parametrize("name", CONS_CASES)
+def test_embedding_classifier_head_alone_matches_reference(name):
+    """oracle.classifier_ce on the 3-layer head against the reference EmbeddingClassifier's own forward, loss_fn and
+    autograd (embedding_classifier.py:49-62,75-77): logits, loss, d loss / d input and the six parameter gradients"""
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    layers = cons_layers(fx)
+    xin, y = torch.from_numpy(fx["head_x"]), torch.from_numpy(fx["y"])
+    assert_close(O.classifier_forward(layers, xin), torch.from_numpy(fx["head_logits"]), 2e-5, "logits")
+    loss, _, gx, pg = O.classifier_ce(layers, xin, y)
+    assert abs(float(loss) - float(fx["head_loss"])) <= 2e-5
+    assert_close(gx, torch.from_numpy(fx["head_gx"]), 2e-5, "d loss / d x")
+    for i, (gW, gb) in enumerate(pg):
+        assert_close(gW, torch.from_numpy(fx[f"head_gw{i}"]), 2e-5, f"dW{i}")
+        assert_close(gb, torch.from_numpy(fx[f"head_gb{i}"]), 2e-5, f"db{i}")
