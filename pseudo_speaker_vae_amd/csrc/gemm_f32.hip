@@ -256,9 +256,15 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
     const float gsc = (epi == EPI_BIAS_RECON) ? d.scale * (d.go ? ldg<float>(d.go) : 1.0f) : 0.f;
     const float kb = (epi == EPI_REPARAM_BWD) ? (d.go ? ldg<float>(d.go) : 1.0f) * d.scale / (float)M : 0.f;
     if (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_BIAS_RECON) {
+        // one 16-byte load where the four columns are whole and aligned, else four loads from clamped columns: never a
+        // branch per element (`if (col + e < N) load` compiles to branch + load + s_waitcnt, four serial round trips);
+        // values of columns >= N are never stored
+        if ((col + 3 < N) && ((reinterpret_cast<uintptr_t>(aux + col) & 15) == 0)) {
+            bias4 = ldg<f32x4>(aux + col);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < N) bias4[e] = ldg<float>(aux + col + e);
+            for (int e = 0; e < 4; ++e) bias4[e] = ldg<float>(aux + (col + e < N ? col + e : N - 1));
+        }
     }
 #pragma unroll
     for (int rr = 0; rr < BM; rr += RSTEP) {
@@ -311,16 +317,21 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
                     if (col + e < N) stg<float>(d.C2 + o + e, gy[e]);
             }
         } else if (epi == EPI_REPARAM_BWD) {  // lightning.py:117-121 + model.py:57-59 differentiated; v = g_z
-            f32x4 gl;
+            f32x4 gl, lv4, mu4, ep4;
+            if (full && ((reinterpret_cast<uintptr_t>(d.aux2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d.aux3) & 15) == 0)) {
+                lv4 = ldg<f32x4>(d.aux2 + o); mu4 = ldg<f32x4>(aux + o); ep4 = ldg<f32x4>(d.aux3 + o);
+            } else {  // clamped columns, no branch per element (values past N are never stored)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const size_t oe = (size_t)row * ldc + (col + e < N ? col + e : N - 1);
+                    lv4[e] = ldg<float>(d.aux2 + oe); mu4[e] = ldg<float>(aux + oe); ep4[e] = ldg<float>(d.aux3 + oe);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (col + e < N) {
-                    const float gz = v[e], l = ldg<float>(d.aux2 + o + e);
-                    v[e] = gz + kb * ldg<float>(aux + o + e);
-                    gl[e] = gz * ldg<float>(d.aux3 + o + e) * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
-                } else {
-                    gl[e] = 0.f;
-                }
+                const float gz = v[e], l = lv4[e];
+                v[e] = gz + kb * mu4[e];
+                gl[e] = gz * ep4[e] * 0.5f * expf(0.5f * l) + 0.5f * kb * (expf(l) - 1.0f);
             }
             if (full) {
                 stg<f32x4>(d.C2 + o, gl);
