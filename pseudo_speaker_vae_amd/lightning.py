@@ -152,13 +152,19 @@ class PseudoSpeakerVAE(_Base):
         if cons is None and self.classifier is None and (vae_trainable or not torch.is_grad_enabled()):
             # fused: forward + ELBO on the GPU, one autograd node (lightning.py:110-124)
             total, recon, kl, _, _, _ = self.model.elbo_step(x, self.kl_loss_weight, self.use_cos_loss)
-        elif (cons is None and self.classifier is not None and not self.multilabel and x.is_cuda and not isinstance(y, dict)
-              and self.classifier.fused_params() is not None and (vae_trainable or not torch.is_grad_enabled())):
-            # fused: forward + ELBO + classifier cross entropy + (when training) the whole backward, one autograd node
-            total, recon, kl, ce, hits, _, _, _ = self.model.elbo_classifier_step(
-                x, y, self.classifier, self.kl_loss_weight, self.classifier_loss_weight, self.use_cos_loss)
-            self.log(f"{prefix}_classifier_acc", hits / x.size(0), sync_dist=True)
-            self.log(f"{prefix}_classifier_loss", ce, sync_dist=True)
+        elif (x.is_cuda and not isinstance(y, dict) and (vae_trainable or not torch.is_grad_enabled())
+              and (self.classifier is None or (not self.multilabel and self.classifier.fused_params() is not None))
+              and (cons is None or cons.fused_ok())):
+            # fused: forward + ELBO + the heads' cross entropies + (when training) the whole backward, one autograd node
+            total, recon, kl, ce, hits, cons_loss, cons_hits, _, _, _ = self.model.elbo_heads_step(
+                x, y, self.classifier, cons, self.kl_loss_weight, self.classifier_loss_weight,
+                self.consitency_loss_weight, self.use_cos_loss)
+            if self.classifier is not None:
+                self.log(f"{prefix}_classifier_acc", hits / x.size(0), sync_dist=True)
+                self.log(f"{prefix}_classifier_loss", ce, sync_dist=True)
+            if cons is not None:
+                self.log(f"{prefix}_consistency", cons_hits / x.size(0), sync_dist=True)
+                self.log(f"{prefix}_consistency_loss", cons_loss, sync_dist=True)
         else:
             x_hat, mu, log_sigma = self(x)
             classifier_loss = 0

@@ -224,36 +224,58 @@ class ELBOStepFunction(torch.autograd.Function):
 
 
 class ELBOClassifierStepFunction(torch.autograd.Function):
-    """total = ELBO(VAE(x), x) + cw * CE(classifier(mu), y) as ONE autograd node, all on the HIP path
-    (lightning.py:67-131 with a single-label classifier head): forward, ELBO, the classifier's cross-entropy step
-    (whose d/dmu becomes the upstream gradient of mu) and the VAE backward run inside forward(); backward() hands the
-    gradients out scaled by d(total).  Returns (total, recon, kl, ce, hits, x_hat, mu, logvar)."""
+    """total = ELBO(VAE(x), x) + cw * CE(classifier(mu), y) + sw * CE(consistency(x_hat), y) as ONE autograd node, all on
+    the HIP path (lightning.py:67-131 with a single-label LatentClassifier head on mu and / or an EmbeddingClassifier
+    consistency head on x_hat): forward, ELBO, the heads' cross-entropy steps (whose d/dmu and d/dx_hat become the
+    upstream gradients of the VAE backward) and the VAE backward run inside forward(); backward() hands the gradients
+    out scaled by d(total).  Returns (total, recon, kl, ce, hits, cons, cons_hits, x_hat, mu, logvar); the entries of an
+    absent head are zeros."""
 
     @staticmethod
     def forward(ctx, x, eps, y, meta, *params):
+        from .embedding_classifier import consistency_ce_raw
         from .latent_classifier import classifier_ce_raw
-        seed, offset, flags, buffers, beta, cw, hidden = meta
+        seed, offset, flags, buffers, beta, cw, hidden, n_clf, sw, n_cons = meta
+        need = list(ctx.needs_input_grad[4:])
         params = [p.detach() for p in params]
-        vae_params, clf_params = params[:_ffi.NPARAM], params[_ffi.NPARAM:]
+        vae_params = params[:_ffi.NPARAM]
+        clf_params = params[_ffi.NPARAM:_ffi.NPARAM + n_clf]
+        cons_params = params[_ffi.NPARAM + n_clf:]
         c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers)
         loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
         ops.elbo(_WsView(c), x, xh, mu, lv, beta, flags, loss3)
-        loss2, g_mu, clf_grads = classifier_ce_raw(mu, y, hidden, clf_params, grad_scale=cw)
+        z4 = torch.zeros(4, dtype=torch.float32, device=x.device)
+        total, ce, hits, cons, cons_hits = loss3[0], z4[0], z4[1], z4[2], z4[3]
+        g_mu = g_xh = None
+        clf_grads, cons_grads = [], [None] * n_cons
+        if n_clf:
+            loss2, g_mu, clf_grads = classifier_ce_raw(mu, y, hidden, clf_params, grad_scale=cw)
+            ce, hits = loss2[0], loss2[1]
+            total = total + cw * ce
+        if n_cons:
+            want = any(need[_ffi.NPARAM + n_clf:])  # the head is frozen inside the VAE's step (lightning.py:48-50)
+            loss2c, g_xh, cg = consistency_ce_raw(xh, y, cons_params, grad_scale=sw, want_param_grads=want)
+            cons, cons_hits = loss2c[0], loss2c[1]
+            total = total + sw * cons
+            if want:
+                cons_grads = cg
         ctx.all_grads = None
-        if any(ctx.needs_input_grad[4:]):
-            grads = _alloc_grads(vae_params)
-            ops.vae_backward(_WsView(c), x, vae_params, xh, mu, lv, grads, g_mu=g_mu, elbo_grad=True, beta=beta, flags=flags)
-            ctx.all_grads = list(grads) + clf_grads
-        total = loss3[0] + cw * loss2[0]
-        recon, kl, ce, hits = loss3[1], loss3[2], loss2[0], loss2[1]
-        ctx.mark_non_differentiable(recon, kl, ce, hits, xh, mu, lv)
-        return total, recon, kl, ce, hits, xh, mu, lv
+        if any(need):
+            grads = [None] * _ffi.NPARAM
+            if any(need[:_ffi.NPARAM]):
+                grads = _alloc_grads(vae_params)
+                ops.vae_backward(_WsView(c), x, vae_params, xh, mu, lv, grads, g_xhat=g_xh, g_mu=g_mu, elbo_grad=True,
+                                 beta=beta, flags=flags)
+            ctx.all_grads = list(grads) + list(clf_grads) + list(cons_grads)
+        recon, kl = loss3[1], loss3[2]
+        ctx.mark_non_differentiable(recon, kl, ce, hits, cons, cons_hits, xh, mu, lv)
+        return total, recon, kl, ce, hits, cons, cons_hits, xh, mu, lv
 
     @staticmethod
     def backward(ctx, g_total, *_):
         grads = ctx.all_grads
         ctx.all_grads = None
-        _scale_grads(grads, g_total.float())
+        _scale_grads([g for g in grads if g is not None], g_total.float())
         return (None, None, None, None, *grads)
 
 
@@ -350,19 +372,36 @@ class VAEModel(nn.Module):
         loss3 = torch.empty(3, device=p0.device)
         return ops.tune_train_step(ws, x, params, grads, ws.new_outputs(), loss3, iters=iters)
 
+    def elbo_heads_step(self, x: torch.Tensor, y: torch.Tensor, classifier=None, consistency=None, beta: float = 1.0,
+                        classifier_weight: float = 1.0, consistency_weight: float = 1.0, use_cos_loss: bool = False,
+                        eps: Optional[torch.Tensor] = None):
+        """fused forward + ELBO + cross entropy of a LatentClassifier on mu and / or of an EmbeddingClassifier on x_hat
+        (lightning.py:67-131; heads the fused steps cover): returns
+        (total, recon, kl, ce, hits, cons, cons_hits, x_hat, mu, logvar)."""
+        hidden, clf_params, cons_params = 0, [], []
+        if classifier is not None:
+            fp = classifier.fused_params()
+            if fp is None:
+                raise _ffi.PsvaeError("elbo_heads_step needs a head LatentClassifier.fused_params() accepts")
+            hidden, clf_params = fp
+        if consistency is not None:
+            if not consistency.fused_ok():
+                raise _ffi.PsvaeError("elbo_heads_step needs a consistency head EmbeddingClassifier.fused_ok() accepts")
+            cons_params = consistency.fused_params()
+        seed, off = self._next_rng(x.shape[0] * self.latent_dim)
+        flags = self.flags | (_ffi.COS_LOSS if use_cos_loss else 0)
+        meta = (seed, off, flags, self._scratch_cache, float(beta), float(classifier_weight), hidden, len(clf_params),
+                float(consistency_weight), len(cons_params))
+        return ELBOClassifierStepFunction.apply(x, eps, y, meta, *self.ordered_params(), *clf_params, *cons_params)
+
     def elbo_classifier_step(self, x: torch.Tensor, y: torch.Tensor, classifier, beta: float = 1.0,
                              classifier_weight: float = 1.0, use_cos_loss: bool = False,
                              eps: Optional[torch.Tensor] = None):
         """fused forward + ELBO + classifier cross entropy on mu (lightning.py:67-131 with a single-label head the
         fused classifier step covers): returns (total, recon, kl, ce, hits, x_hat, mu, logvar)."""
-        fp = classifier.fused_params()
-        if fp is None:
-            raise _ffi.PsvaeError("elbo_classifier_step needs a head LatentClassifier.fused_params() accepts")
-        hidden, clf_params = fp
-        seed, off = self._next_rng(x.shape[0] * self.latent_dim)
-        flags = self.flags | (_ffi.COS_LOSS if use_cos_loss else 0)
-        meta = (seed, off, flags, self._scratch_cache, float(beta), float(classifier_weight), hidden)
-        return ELBOClassifierStepFunction.apply(x, eps, y, meta, *self.ordered_params(), *clf_params)
+        total, recon, kl, ce, hits, _, _, xh, mu, lv = self.elbo_heads_step(
+            x, y, classifier, None, beta, classifier_weight, 1.0, use_cos_loss, eps)
+        return total, recon, kl, ce, hits, xh, mu, lv
 
     def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
                   eps: Optional[torch.Tensor] = None):

@@ -377,9 +377,9 @@ def test_training_step_classifier_branch_fused_equals_torch_ops():
                            classifier_loss_weight=0.3).to("cuda:0")
     x, y = torch.randn(B, D, device="cuda:0"), torch.randint(0, 3, (B,), device="cuda:0")
     eps = torch.randn(B, Z, device="cuda:0")
-    orig_forward, orig_fused = mod.model.forward, mod.model.elbo_classifier_step
+    orig_forward, orig_fused = mod.model.forward, mod.model.elbo_heads_step
     mod.model.forward = lambda xx: orig_forward(xx, eps=eps)  # same noise in both runs
-    mod.model.elbo_classifier_step = lambda *a, **k: orig_fused(*a, eps=eps, **k)
+    mod.model.elbo_heads_step = lambda *a, **k: orig_fused(*a, eps=eps, **k)
 
     def run(fused):
         mod.zero_grad(set_to_none=True)
@@ -401,7 +401,7 @@ def test_training_step_classifier_branch_fused_equals_torch_ops():
 
 @pytest.mark.parametrize("name", ["clfstep_d256_z64_b24_h128", "clfstep_d256_z64_b19_lin"])
 def test_training_step_with_classifier_head_matches_reference_golden(name):
-    """the fused HIP training step with a classifier head (VAEModel.elbo_classifier_step behind training_step) against
+    """the fused HIP training step with a classifier head (VAEModel.elbo_heads_step behind training_step) against
     the fixture generated from the reference's own training_step + backward"""
     import numpy as np
     import torch
@@ -425,8 +425,8 @@ def test_training_step_with_classifier_head_matches_reference_golden(name):
             l.bias.copy_(torch.from_numpy(fx[f"cls_b{i}"]))
     mod = mod.to("cuda:0")
     eps = torch.from_numpy(fx["eps"]).cuda()
-    orig = mod.model.elbo_classifier_step
-    mod.model.elbo_classifier_step = lambda *a, **k: orig(*a, eps=eps, **k)
+    orig = mod.model.elbo_heads_step
+    mod.model.elbo_heads_step = lambda *a, **k: orig(*a, eps=eps, **k)
     out = mod.training_step((torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["y"]).cuda()), 0)
     out["loss"].backward()
     assert abs(float(out["loss"]) - float(fx["total"])) <= REL_TOL * max(1.0, abs(float(fx["total"])))
@@ -550,8 +550,8 @@ def test_training_step_with_consistency_head_matches_reference_golden(name, tmp_
             l.bias.copy_(torch.from_numpy(fx[f"cls_b{i}"]))
     mod = mod.to(DEV)
     eps = torch.from_numpy(fx["eps"]).to(DEV)
-    orig = mod.model.forward
-    mod.model.forward = lambda xx: orig(xx, eps=eps)
+    orig = mod.model.elbo_heads_step  # training_step takes the fused two-head node: give it the fixture's noise
+    mod.model.elbo_heads_step = lambda *a, **k: orig(*a, eps=eps, **k)
     out = mod.training_step((torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["y"]).to(DEV)), 0)
     out["loss"].backward()
     assert abs(float(out["loss"]) - float(fx["total"])) <= REL_TOL * max(1.0, abs(float(fx["total"])))
@@ -591,3 +591,66 @@ def test_embedding_classifier_training_step_matches_reference_golden(name):
         assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"head_gb{i}"]), REL_TOL, f"db{i}")
     opt = head.configure_optimizers()
     assert isinstance(opt, torch.optim.Adam) and len(opt.param_groups[0]["params"]) == 6
+
+
+@pytest.mark.parametrize("with_clf", [False, True])
+def test_training_step_consistency_fused_node_equals_separate_nodes(with_clf):
+    """training_step with a consistency head (and optionally a latent classifier): the single fused autograd node
+    (VAEModel.elbo_heads_step) gives the same losses, logged values and gradients as the branch that chains
+    VAEForwardFunction + the heads' own nodes + torch-op ELBO; validation_step under no_grad leaves no gradients"""
+    from ps_vae.embedding_classifier.embedding_classifier import EmbeddingClassifier
+    from ps_vae.lightning import PseudoSpeakerVAE
+    D, Z, B = 128, 32, 150
+    torch.manual_seed(4)
+    kw = dict(classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=64, activation="relu"),
+              classifier_loss_weight=0.4) if with_clf else {}
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), consistency_loss_weight=0.6, kl_loss_weight=0.8, **kw)
+    head = EmbeddingClassifier(D, 3, 64)
+    with torch.no_grad():
+        for q in head.parameters():
+            q.mul_(3.0)
+            q.requires_grad = False
+    mod.consistency_classifier = head.eval()
+    mod = mod.to(DEV)
+    x, y = torch.randn(B, D, device=DEV), torch.randint(0, 3, (B,), device=DEV)
+    eps = torch.randn(B, Z, device=DEV)
+    orig_forward, orig_fused = mod.model.forward, mod.model.elbo_heads_step
+    mod.model.forward = lambda xx: orig_forward(xx, eps=eps)
+    mod.model.elbo_heads_step = lambda *a, **k: orig_fused(*a, eps=eps, **k)
+
+    def run(fused):
+        mod.zero_grad(set_to_none=True)
+        mod.logged.clear()
+        if not fused:
+            # the first fused_ok() query of a step is the fused-node test (answer no: take the branch of separate
+            # nodes), the later one is the head's own fused step inside that branch (answer yes)
+            real, calls = head.fused_ok, {"n": 0}
+
+            def fused_ok_after_first():
+                calls["n"] += 1
+                return calls["n"] > 1
+            mod.consistency_classifier.fused_ok = fused_ok_after_first
+        out = mod.training_step((x, y), 0)
+        out["loss"].backward()
+        if not fused:
+            assert calls["n"] >= 2
+            mod.consistency_classifier.fused_ok = real
+        logged = {k: float(v) for k, v in mod.logged.items()}
+        return float(out["loss"]), logged, [None if p.grad is None else p.grad.clone() for p in mod.parameters()]
+
+    lf, logf, gf = run(True)
+    lt, logt, gt = run(False)
+    assert abs(lf - lt) <= 1e-5 * max(1.0, abs(lt))
+    assert set(logf) == set(logt)
+    for k in logf:
+        assert abs(logf[k] - logt[k]) <= 1e-5 * max(1.0, abs(logt[k])), k
+    for a, b in zip(gf, gt):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert_close(a.cpu(), b.cpu(), 2e-4, "fused two-head node vs separate nodes")
+    assert all(q.grad is None for q in mod.consistency_classifier.parameters())
+    mod.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        v = mod.validation_step((x, y), 0)
+    assert torch.isfinite(v["loss"]) and all(p.grad is None for p in mod.parameters())
+    assert "val_consistency_loss" in mod.logged and ("val_classifier_loss" in mod.logged) == with_clf
