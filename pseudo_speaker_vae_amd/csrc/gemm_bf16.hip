@@ -39,7 +39,9 @@ __device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned
 // STAGED: the 128x128 tile's operand panels go through LDS (each element fetched once per workgroup, whole 128-B
 // lines per 8 lanes) instead of every wave fetching its own fragments -- at these sizes the bf16 GEMMs are pure
 // operand traffic (the MFMAs of a 2-GFLOP launch take 1 us), so bytes per workgroup decide the time.
-template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED>
+// CT: launches that carry a conditional table get their own instantiation (the table tile goes through LDS, below);
+// the CT = false code is what every other launch has always run.
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED, bool CT>
 __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     constexpr int NW = WM * WN * KS;
     static_assert(NW == 4, "4 waves per workgroup");
@@ -215,6 +217,24 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     }
 
     // ---- epilogue ----
+    // CT: the conditional table tile [6][BN] of this workgroup's columns, one 16-byte piece per thread, in flight while
+    // the accumulators go to LDS; parked in LDS ([7][BN], row 6 = zeros for unknown labels) and read by label in the row
+    // loop.  (The register version -- six preloaded vectors and two select chains per row -- cost 6.4 us on the first
+    // encoder layer and 4.5 us on decoder.0; this one 3.3 / 1.5 us.  Same additions in the same order: same bits.)
+    constexpr int CTQ = BN / 4;
+    f32x4 ctpre = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CT) {
+        if (d.ctab && tid < 6 * CTQ) {
+            const int colj = n0 + 4 * (tid % CTQ);
+            const float* tp = d.ctab + (size_t)(tid / CTQ) * N;
+            if (colj + 3 < N && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.ctab) & 15) == 0)) {
+                ctpre = ldgb<f32x4>(tp + colj);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ctpre[e] = ldgb<float>(tp + (colj + e < N ? colj + e : N - 1));
+            }
+        }
+    }
     constexpr int SC = BN + 4;
     float* __restrict__ Cs = smem + ks * (BM * SC);
 #pragma unroll
@@ -235,6 +255,13 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             if (q == 0) csum_s[ks * BM + wm * 16 * TM + 16 * m + r] = s;
         }
     }
+    float* __restrict__ ct_s = smem + KS * (BM * SC) + KS * BM + 8;
+    if constexpr (CT) {
+        if (d.ctab) {
+            if (tid < 6 * CTQ) *reinterpret_cast<f32x4*>(ct_s + (tid / CTQ) * BN + 4 * (tid % CTQ)) = ctpre;
+            if (tid < CTQ) *reinterpret_cast<f32x4*>(ct_s + 6 * BN + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
     const int epi = d.epi;
     constexpr int CQ = BN / 4;
@@ -249,12 +276,14 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ct[6] = {zero4, zero4, zero4, zero4, zero4, zero4};  // this thread's 4 columns of the conditional table
-    if (d.ctab) {
+    if constexpr (!CT) {
+        if (d.ctab) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+            for (int c = 0; c < 6; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e < N) ct[c][e] = ldgb<float>(d.ctab + (size_t)c * N + col + e);
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) ct[c][e] = ldgb<float>(d.ctab + (size_t)c * N + col + e);
+        }
     }
     float sq = 0.f;
     const float gsc = (epi == BEPI_RECON) ? d.scale * (d.go ? ldgb<float>(d.go) : 1.0f) : 0.f;
@@ -271,8 +300,14 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             v += bias4;
             if (d.ctab) {  // one-hot conditioning: + table[gender] + table[3 + age], table columns preloaded above
                 const int g = d.gender[row], a = d.age[row];
-                v += (g == 0 ? ct[0] : g == 1 ? ct[1] : g == 2 ? ct[2] : zero4);
-                v += (a == 0 ? ct[3] : a == 1 ? ct[4] : a == 2 ? ct[5] : zero4);
+                if constexpr (CT) {
+                    const int gi = (unsigned)g < 3u ? g : 6, ai = (unsigned)a < 3u ? 3 + a : 6;
+                    v += *reinterpret_cast<const f32x4*>(ct_s + gi * BN + 4 * c4);
+                    v += *reinterpret_cast<const f32x4*>(ct_s + ai * BN + 4 * c4);
+                } else {
+                    v += (g == 0 ? ct[0] : g == 1 ? ct[1] : g == 2 ? ct[2] : zero4);
+                    v += (a == 0 ? ct[3] : a == 1 ? ct[4] : a == 2 ? ct[5] : zero4);
+                }
             }
             if (epi == BEPI_RELU) {
 #pragma unroll
@@ -379,7 +414,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     }
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED>
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED, bool CT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
@@ -392,13 +427,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch)
     const int ksg = STAGED ? lt / tiles_mn : 0;  // cross-workgroup k slice (staged kernel only)
     lt -= ksg * tiles_mn;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    gemm_tile_bf16<TM, TN, WM, WN, KS, D, STAGED>(d, tm, tn, ksg, smem);
+    gemm_tile_bf16<TM, TN, WM, WN, KS, D, STAGED, CT>(d, tm, tn, ksg, smem);
 }
 
-template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED = false>
-static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED, bool CT>
+static hipError_t launch_bf_ct(GemmBatchBf& b, hipStream_t stream) {
     constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
-    constexpr size_t lds_epi = (size_t)(KS * BM * (BN + 4) + KS * BM + 8) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)(KS * BM * (BN + 4) + KS * BM + 8 + (CT ? 7 * BN : 0)) * sizeof(float);  // CT: + the table tile
     constexpr size_t lds_stage = STAGED ? (size_t)2 * (BM + BN) * (64 + 8) * 2 : 0;  // two buffers of A and B panels
     constexpr size_t lds = lds_epi > lds_stage ? lds_epi : lds_stage;
     int t = 0;
@@ -413,7 +448,7 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
     b.total_tiles = t;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 96 * 1024 ? lds : 96 * 1024));
         if (e != hipSuccess) return e;
         attr_done = true;
@@ -423,8 +458,16 @@ static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
     static const bool cap_on = getenv("PSVAE_BF16_CAP") != nullptr && atoi(getenv("PSVAE_BF16_CAP")) != 0;  // measured: slower here
     size_t lds_req = lds;
     if (cap_on && t > 256 && lds_req < 82 * 1024) lds_req = 82 * 1024;
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED>), dim3(t), dim3(256), lds_req, stream, b);
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>), dim3(t), dim3(256), lds_req, stream, b);
     return hipGetLastError();
+}
+
+template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED = false>
+static hipError_t launch_bf(GemmBatchBf& b, hipStream_t stream) {
+    bool ct = false;
+    for (int i = 0; i < b.n; ++i) ct = ct || (b.d[i].ctab != nullptr);
+    return ct ? launch_bf_ct<TM, TN, WM, WN, KS, D, STAGED, true>(b, stream)
+              : launch_bf_ct<TM, TN, WM, WN, KS, D, STAGED, false>(b, stream);
 }
 
 // config choice: wide register tiles (the bf16 pipe is 16x faster than fp32, the fragment loads are the
