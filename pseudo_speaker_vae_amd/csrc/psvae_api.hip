@@ -697,7 +697,16 @@ int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n) {
     return 0;
 }
 
-static const int64_t DECODE_CHUNK = 65536;
+// rows per pass (PSVAE_DECODE_CHUNK: tuning; a multiple of 128)
+static int64_t decode_chunk() {
+    static const int64_t v = [] {
+        const char* e = getenv("PSVAE_DECODE_CHUNK");
+        const long long n = e ? atoll(e) : 0;
+        return (int64_t)((n >= 128 && n % 128 == 0) ? n : 65536);
+    }();
+    return v;
+}
+#define DECODE_CHUNK decode_chunk()
 
 size_t psvae_decode_scratch_bytes(int64_t N) {
     if (N <= 0) return 0;

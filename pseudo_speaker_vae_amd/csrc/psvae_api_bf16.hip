@@ -320,7 +320,16 @@ int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_para
 // ---- decode-only sampling in bf16 (VAEModel.decode, model.py:65-69; SURVEY 8b psvae_decode_bf16) ----------------
 // Every GEMM reads its activation row-major, so this path needs no second layout: z and the three decoder weights are
 // cast to bf16 (one launch per call / per chunk), the hidden activations stay bf16, biases, accumulation and x_hat fp32.
-static const int64_t DECODE_CHUNK_BF = 131072;
+// rows per pass (PSVAE_DECODE_CHUNK_BF: tuning; a multiple of 128)
+static int64_t decode_chunk_bf() {
+    static const int64_t v = [] {
+        const char* e = getenv("PSVAE_DECODE_CHUNK_BF");
+        const long long n = e ? atoll(e) : 0;
+        return (int64_t)((n >= 128 && n % 128 == 0) ? n : 131072);
+    }();
+    return v;
+}
+#define DECODE_CHUNK_BF decode_chunk_bf()
 
 size_t psvae_decode_bf16_scratch_bytes(int64_t N, int64_t D, int64_t Z) {
     if (N <= 0 || D <= 0 || Z <= 0) return 0;
