@@ -636,6 +636,19 @@ void finalize_batch(GemmBatch& b, int cfg) {
                     const double e = launch_cost(b, ct, co);
                     if (e < best) { best = e; pick_tn = ct; pick_other = co; }
                 }
+            if (has_tn && has_other && pick_other != pick_tn) {
+                // Two corrections the makespan model cannot see (one workgroup per CU at a time, a fixed cost per
+                // workgroup), both measured on cfg2's backward, together 150.1 -> 144.5 us/step untuned:
+                //  * forward/dgrad problems with k <= 64 have no k loop to amortise a 64x64 tile's LDS round trip: the
+                //    weight gradients' small config serves them too, as many co-resident workgroups
+                //    (heads' dgrad beside their weight gradients: <8,8> uncapped 10.3 us, <8,6> 14.1 us);
+                //  * near a tie one config for both classes wins: <c,c> is half the code of a mixed pair, and a
+                //    launch starts from a cold instruction cache (<8,8> 8.0 us, <8,1> 9.1 us on decoder.0's backward)
+                bool short_k = true;
+                for (int i = 0; i < b.n; ++i)
+                    if (b.d[i].kind != GK_TN && b.d[i].K > 64) short_k = false;
+                if (short_k || launch_cost(b, pick_tn, pick_tn) <= 1.02 * best) pick_other = pick_tn;
+            }
             std::lock_guard<std::mutex> lk(memo_mu);
             Memo& m = memo[memo_n < 64 ? memo_n++ : (memo_n = 1, 0)];  // full: start over
             memcpy(m.key, key, sizeof(key));
@@ -703,7 +716,8 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     static const int lds_min = env_int("PSVAE_LDS_MIN", 0);  // tuning
     if ((size_t)lds_min > lds) lds = lds_min;
     static const int cap_default = env_int("PSVAE_CAP_DEFAULT", 1);  // untuned launches with more workgroups than CUs
-    const bool cap = b.hint_cap == 1 || (b.hint_cap == 0 && cap_default && b.total_tiles > 256);
+    bool many_small = c0 == 8 && c1 == 8;  // 16x32 tiles: light workgroups, meant to be co-resident (see finalize_batch)
+    const bool cap = b.hint_cap == 1 || (b.hint_cap == 0 && cap_default && b.total_tiles > 256 && !many_small);
     if (cap && lds < 82 * 1024) lds = 82 * 1024;
     {   // decode-sized: >= 4 tiles per CU, one config, no weight gradients, no k split across workgroups
         static const int persist_min = env_int("PSVAE_PERSIST_MIN", 1024);
