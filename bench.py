@@ -282,7 +282,11 @@ def main():
                        "launch": mode, "parallelism": f"dp{world}", "launch_plan": plan},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5)},
+                         "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5),
+                         # what `achieved` divides by: HIP-event time of the WHOLE step (every launch of it, not only
+                         # the GEMM kernel -- the committed rocprofv3 summary has the per-kernel averages)
+                         "scope": "whole step: all launches of psvae_train_step (11 grouped-GEMM + weight transpose + "
+                                  "bottleneck kernel at fp32), HIP events on the launch stream"},
             "loss": [round(v, 6) for v in loss],
         }
         if world == 1 and not args.no_cpu_baseline:
