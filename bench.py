@@ -4,18 +4,30 @@
 GPU, fp32, synthetic N(0,1) embeddings already resident in HBM.
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+N > 1 runs one rank per GPU over RCCL.  Two ways to start it, same result:
+  * `python bench.py --gpus N ...` by itself: this process never touches the GPU; it starts N fresh child
+    ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), waits for them, relays rank
+    0's JSON line and exits non-zero if any rank failed (or if the box has fewer than N GPUs);
+  * `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`: the ranks are already there (WORLD_SIZE is set), each runs its share.
 
 Prints ONE JSON line (rank 0).  `value` = whole-job embeddings/s; weak scaling (1024 rows per GPU).
 `roofline`: algorithmic FLOPs of the step (7,143,424 FLOP/embedding at cfg2) over the
 step duration measured with HIP events on the launch stream, against the fp32 MFMA peak.
 `cpu_baseline`: the CPU oracle (a port of the reference's math, oracle/psvae_oracle.py) timed on
 this box's host cores over a bounded sample of the same workload (N = 1, rank 0 only).
+
+Other workloads (not the headline): --workload decode (cfg5 decode-only sampling), --workload langevin (cfg5
+conditional sampling: the classifier-guided Langevin chain of inference.py:72-103 + one decode).
+--stub: CPU rehearsal of the launcher / barrier / max-over-ranks aggregation with gloo and a fake step (tests only;
+its `value` means nothing).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +40,25 @@ if REPO not in sys.path:
 H = 512
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (spec figure without 2:1 sparsity)
+PEAK_FP32_VALU_TFLOPS = 157.3   # fp32 vector peak (same table): the Langevin chain is per-lane VALU work
+PEAK_HBM_GBS = 8000.0
 
 
 def flop_per_embedding(D: int, Z: int) -> int:
     fwd = 2 * (D * H + H * H + H * Z) + (Z * H + H * H + H * D)
     bwd = 2 * fwd - 2 * D * H
     return 2 * (fwd + bwd)
+
+
+def config_label(D, Z, B, dtype, cond) -> str:
+    """BASELINE.json config name of a training shape, or "custom" (the label never claims a config the shape is not)"""
+    if (D, Z, B, dtype, cond) == (256, 64, 1024, "f32", False):
+        return "cfg2"
+    if (D, Z, B, dtype, cond) == (256, 64, 4096, "bf16", True):
+        return "cfg3"
+    if (D, Z, B, dtype, cond) == (512, 128, 1024, "f32", False):
+        return "cfg4 (per-GPU shape)"
+    return "custom"
 
 
 def cpu_baseline(D, Z, B, steps=40, warmup=3):
@@ -58,11 +83,191 @@ def cpu_baseline(D, Z, B, steps=40, warmup=3):
             "kind": "port", "sample": f"{n} steps of fwd+ELBO+bwd at B={B}, D={D}, Z={Z} (oracle, torch-CPU fp32)"}
 
 
-def bench_decode(args, world, rank, dev):
+# --------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no ranks around yet
+# --------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(args) -> int:
+    """Start args.gpus fresh rank processes of this script and relay rank 0's JSON line.  Runs BEFORE anything in this
+    process touches the GPU (device_count() does not initialise it on this image), so no process that has used the
+    GPU ever forks or execs."""
+    n = args.gpus
+    if not args.stub:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} needs {n} GPUs on this node, found {have}: nothing was run", file=sys.stderr)
+            return 2
+        from pseudo_speaker_vae_amd import build
+        build.build(verbose=False)  # once, here: the ranks find a library that matches the sources
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PSVAE_BENCH_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with code {code}", file=sys.stderr)
+        if pending and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"[bench] ranks {sorted(pending)} still running after {args.launch_timeout} s", file=sys.stderr)
+            for r in pending:  # a rank died or hung: the others would wait in a collective forever
+                procs[r].terminate()
+            t_kill = time.time() + 10
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if pending:
+            time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if rc == 0 and line is None:
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------------------
+# one rank
+# --------------------------------------------------------------------------------------------------------------
+class Rank:
+    """process-group plumbing of one rank: init, fence (barrier + device sync), max over ranks, teardown"""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.stub = args.stub
+        self.dev = torch.device("cpu") if args.stub else torch.device("cuda", self.local_rank)
+        self.pg = None
+        self.use_dist = self.world > 1 or os.environ.get("PSVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL smoke
+        if not self.stub:
+            torch.cuda.set_device(self.local_rank)
+        if self.use_dist:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.stub:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+            self.pg = dist.group.WORLD
+
+    def barrier(self):
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def fence(self):
+        self.barrier()
+        if not self.stub:
+            torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, *vals):
+        if self.world == 1:
+            return list(vals)
+        import torch.distributed as dist
+        t = torch.tensor(vals, dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def close(self):
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def timed(rk: Rank, step, steps: int, warmup: int):
+    """W untimed steps, then EXACTLY `steps` between two fences; returns (wall s, device ms), max over ranks"""
+    for i in range(warmup):
+        step(i)
+    rk.fence()
+    if rk.stub:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        rk.fence()
+        wall = time.perf_counter() - t0
+        dev_ms = wall * 1e3
+    else:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            step(warmup + i)
+        ev1.record()
+        rk.fence()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+    wall, dev_ms = rk.max_over_ranks(wall, dev_ms)
+    return wall, dev_ms
+
+
+def bench_stub(args, rk: Rank):
+    """the launcher / aggregation path on CPU with gloo: each rank "trains" a fake flat gradient and averages it"""
+    import torch.distributed as dist
+    B = args.batch
+    grad = torch.full((1024,), float(rk.rank + 1))
+
+    if os.environ.get("PSVAE_BENCH_STUB_FAIL_RANK") == str(rk.rank):  # test hook: this rank dies before the collective
+        os._exit(3)
+
+    def step(i):
+        grad.fill_(float(rk.rank + 1))
+        time.sleep(0.001 * (1 + rk.rank))  # ranks of unequal speed: the max over ranks must win
+        if rk.world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            grad.mul_(1.0 / rk.world)
+    wall, dev_ms = timed(rk, step, args.steps, args.warmup)
+    if rk.rank == 0:
+        print(json.dumps({
+            "metric": "speaker-embeddings/sec (fwd+bwd)", "value": round(B * rk.world * args.steps / wall, 1),
+            "unit": "speaker-embeddings/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "STUB (CPU/gloo rehearsal of the launcher and aggregation path; not a measurement)",
+                       "parallelism": f"dp{rk.world}", "allreduce": "gloo sum + scale"},
+            "stub_grad_mean": float(grad[0])}), flush=True)
+
+
+def bench_decode(args, rk: Rank):
     """cfg5: decode-only sampling (inference.py:22-25): z ~ N(0, I) from the device Philox stream, x_hat =
     decoder(z).  Rows are split evenly over the ranks; no collective."""
-    from pseudo_speaker_vae_amd import ops
+    from pseudo_speaker_vae_amd import _ffi, ops
     from pseudo_speaker_vae_amd.model import VAEModel
+    dev, world, rank = rk.dev, rk.world, rk.rank
     D, Z = args.input_dim, args.latent_dim
     n = args.samples // world
     torch.manual_seed(0)
@@ -70,47 +275,23 @@ def bench_decode(args, world, rank, dev):
     dec = [p.detach().to(dev) for p in m.ordered_params()[12:]]
     out = torch.empty(n, D, device=dev)
     z = torch.empty(n, Z, device=dev)
-    scratch = torch.empty(1, dtype=torch.uint8, device=dev)
+    bf16 = args.dtype == "bf16"
+    nbytes = _ffi.lib().psvae_decode_bf16_scratch_bytes(n, D, Z) if bf16 else _ffi.lib().psvae_decode_scratch_bytes(n)
+    scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
 
     def step(i):
-        from pseudo_speaker_vae_amd import _ffi
         _ffi.check(_ffi.lib().psvae_philox_normal_f32(z.data_ptr(), n * Z, 1234 + rank, i * ((n * Z + 3) // 4),
                                                       torch.cuda.current_stream().cuda_stream), "philox")
         if bf16:
-            ops.decode_bf16(z, dec, D, out=out, scratch=step.scratch)
+            ops.decode_bf16(z, dec, D, out=out, scratch=scratch)
         else:
-            ops.decode(z, dec, D, out=out, scratch=step.scratch)
-    from pseudo_speaker_vae_amd import _ffi
-    bf16 = args.dtype == "bf16"
-    nbytes = _ffi.lib().psvae_decode_bf16_scratch_bytes(n, D, Z) if bf16 else _ffi.lib().psvae_decode_scratch_bytes(n)
-    step.scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-
-    def fence():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            ops.decode(z, dec, D, out=out, scratch=scratch)
     steps, warm = max(1, min(args.steps, 20)), max(1, min(args.warmup, 3))
-    for i in range(warm):
-        step(i)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(steps):
-        step(warm + i)
-    ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = t.tolist()
+    wall, dev_ms = timed(rk, step, steps, warm)
     if rank == 0:
         fpe = 2 * (Z * H + H * H + H * D)  # 851,968 FLOP per decoded embedding at cfg5
         achieved = fpe * n / (dev_ms / 1e3 / steps) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         print(json.dumps({
             "metric": "speaker-embeddings/sec (decode)", "value": round(n * world * steps / wall, 1),
             "unit": "speaker-embeddings/s", "n_gpus": world, "steps": steps, "warmup": warm,
@@ -119,148 +300,167 @@ def bench_decode(args, world, rank, dev):
             "config": {"workload": f"cfg5: decode-only sampling, {n * world} rows per step ({n}/GPU), d_in={D} z={Z}, "
                                    "Philox z on device + 3-layer decoder"
                                    + (" (bf16 operands / fp32 accumulate)" if bf16 else ""), "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3),
-                         "peak": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS), 4),
-                         "traffic": None, "flop_per_embedding": fpe}}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None, "flop_per_embedding": fpe}}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
-    ap.add_argument("--input-dim", type=int, default=256)
-    ap.add_argument("--latent-dim", type=int, default=64)
-    ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
-    ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="bf16 = config 3 arithmetic (bf16 MFMA operands, fp32 accumulate and master weights)")
-    ap.add_argument("--cond", action="store_true", help="config 3: one-hot gender+age conditioning (needs --dtype bf16)")
-    ap.add_argument("--workload", choices=["train", "decode"], default="train",
-                    help="train = cfg2 (headline); decode = cfg5: decode-only sampling, --samples rows in total")
-    ap.add_argument("--samples", type=int, default=1_000_000, help="decode workload: rows over all GPUs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tune", action="store_true", help="skip the launch-plan autotuning (heuristic configs)")
-    ap.add_argument("--plan", default="", help="use this launch plan (text form printed as config.launch_plan)")
-    args = ap.parse_args()
+def bench_langevin(args, rk: Rank):
+    """cfg5, conditional leg (inference.py:29-110): z0 ~ N(0, I); `--langevin-steps` steps of
+    z += 0.5 s^2 grad[log p(y|z) + log p(z)] + s w noise with a LatentClassifier head (Z -> hidden -> C), all inside
+    ONE kernel launch (one lane per latent row), then one decode of the final z.  Rows are split over the ranks."""
+    from pseudo_speaker_vae_amd import _ffi, ops
+    from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
+    from pseudo_speaker_vae_amd.model import VAEModel
+    dev, world, rank = rk.dev, rk.world, rk.rank
+    D, Z, T, hidden, C_ = args.input_dim, args.latent_dim, args.langevin_steps, 128, 3
+    n = args.samples // world
+    torch.manual_seed(0)
+    m = VAEModel(D, Z)
+    clf = LatentClassifier(Z, C_, num_layers=2, hidden_dim=hidden)
+    dec = [p.detach().to(dev) for p in m.ordered_params()[12:]]
+    W1, b1, W2, b2 = [p.detach().to(dev).contiguous() for p in clf.parameters()]
+    z = torch.empty(n, Z, device=dev)
+    out = torch.empty(n, D, device=dev)
+    scratch = torch.empty(int(_ffi.lib().psvae_decode_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    nblk = (n * Z + 3) // 4
+    L = _ffi.lib()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
-    from pseudo_speaker_vae_amd import build
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pg = None
-    use_dist = world > 1 or os.environ.get("PSVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL smoke of the DDP path
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-        pg = dist.group.WORLD
+    def step(i):
+        s = torch.cuda.current_stream().cuda_stream
+        base = (i * (T + 1)) * nblk
+        _ffi.check(L.psvae_philox_normal_f32(z.data_ptr(), n * Z, 99 + rank, base, s), "philox")
+        _ffi.check(L.psvae_langevin_f32(n, Z, hidden, C_, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                        z.data_ptr(), 1, 0.05, 1.0, T, None, 99 + rank, base + nblk, None, s), "langevin")
+        ops.decode(z, dec, D, out=out, scratch=scratch)
+    steps, warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
+    wall, dev_ms = timed(rk, step, steps, warm)
     if rank == 0:
+        # per row and Langevin step: classifier forward + backward 2*(2*Z*hidden + 2*hidden*C) MAC-flops, prior, update
+        fpr = 2 * 2 * (Z * hidden + hidden * C_) + 6 * Z
+        flops = (fpr * T + 2 * (Z * H + H * H + H * D)) * n
+        achieved = flops / (dev_ms / 1e3 / steps) / 1e12
+        print(json.dumps({
+            "metric": "speaker-embeddings/sec (conditional sampling)", "value": round(n * world * steps / wall, 1),
+            "unit": "speaker-embeddings/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg5 conditional: {n * world} rows ({n}/GPU) x {T} Langevin steps "
+                                   f"(LatentClassifier {Z}->{hidden}->{C_}, target class 1) + one decode, d_in={D} z={Z}",
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "valu-fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "flop_per_row_step": fpr,
+                         "note": "the chain keeps z in registers: HBM traffic is one read + one write of z per launch; "
+                                 "the bound is the per-lane fp32 FMA rate (vector peak = 157.3 TFLOP/s)"}}), flush=True)
+
+
+def committed_traffic(D, Z, B, dtype, plan):
+    """HBM-side bytes per step from the committed rocprofv3 PMC passes -- reported with its provenance, and only when
+    the committed passes were taken on this shape; never presented as measured in this run"""
+    for name in ("r02_cfg2_pmc.json", "r01_cfg2_pmc.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if (D, Z, B, dtype) == (256, 64, 1024, "f32") and os.path.exists(path):
+            try:
+                rec = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            same_plan = rec.get("launch_plan") in (None, plan)
+            return rec.get("hbm_bytes_per_step"), f"profiles/{name} (separate rocprofv3 --pmc passes of `python bench.py`" \
+                + ("" if same_plan else "; taken under a DIFFERENT launch plan than this run's") + ")"
+    return None, None
+
+
+def run_rank(args) -> int:
+    rk = Rank(args)
+    world, rank, dev = rk.world, rk.rank, rk.dev
+    if world != args.gpus:
+        args.gpus = world
+    if args.stub:
+        bench_stub(args, rk)
+        rk.close()
+        return 0
+    from pseudo_speaker_vae_amd import build
+    if rank == 0 and os.environ.get("PSVAE_BENCH_CHILD") != "1":
         build.build(verbose=False)  # no-op when the shipped .so matches the sources (content hash)
-    if use_dist:
-        dist.barrier()              # nobody loads the library before rank 0 has (re)built it
+    rk.barrier()                    # nobody loads the library before rank 0 has (re)built it
     if args.workload == "decode":
-        return bench_decode(args, world, rank, dev)
+        bench_decode(args, rk)
+        rk.close()
+        return 0
+    if args.workload == "langevin":
+        bench_langevin(args, rk)
+        rk.close()
+        return 0
 
     from pseudo_speaker_vae_amd.engine import TrainEngine
     D, Z, B = args.input_dim, args.latent_dim, args.batch
-    eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=pg, dtype=args.dtype,
+    eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=rk.pg, dtype=args.dtype,
                       conditional=args.cond)
     g = torch.Generator().manual_seed(1234 + rank)  # each rank its own shard of synthetic rows
     x = torch.randn(B, D, generator=g).to(dev)
     if args.cond:
         eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
 
-    plan = "untuned"
     if args.plan:
-        plan = eng.tune(x, plan=args.plan)  # a plan tuned by an earlier run (profiling runs reuse the bench's)
-    elif not args.no_tune:
-        plan = eng.tune(x)  # launch-plan autotuning, once per shape, outside the timed region
+        plan = eng.tune(x, plan=args.plan)       # an explicit plan (text form printed as config.launch_plan)
+    elif args.tune:
+        plan = eng.tune(x, force=True)           # measure now (a few seconds, outside the timed region)
+    else:
+        plan = eng.tune(x)                       # the committed plan for this GPU model and shape, else heuristics
     mode = args.mode
+    allreduce = "none"
     if mode == "auto":
         mode = "graph"
-    if mode == "graph" and pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
+    if mode == "graph" and rk.pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
         mode = "graph-ddp-overlap"  # two captured halves around two RCCL all-reduces (decoder bucket overlapped)
+        allreduce = "2 buckets, eager between two graphs"
         eng.capture_ddp(x)
 
-        def step():
+        def step(i):
             eng.replay_ddp()
             if args.with_adam:
                 eng.optimizer_step()
     elif mode == "graph":
         in_graph = os.environ.get("PSVAE_DDP_IN_GRAPH", "0")  # 0 (default): the all-reduce is issued after the graph -- the
-        # plain, everywhere-proven RCCL usage; 1: captured inside the graph (36 us/step less at 1 rank, but multi-rank
-        # capture could not be rehearsed on the 1-GPU box, so it is opt-in); 2: decoder bucket as a parallel graph branch
-        if pg is not None and in_graph in ("1", "2"):
+        # plain, everywhere-proven RCCL usage; 1: captured inside the graph; 2: decoder bucket as a parallel graph branch
+        if rk.pg is not None and in_graph in ("1", "2"):
             try:
                 eng.capture_with_collective(x, overlap=(in_graph == "2"))
                 mode = "graph(all-reduce inside" + (", decoder bucket overlapped)" if in_graph == "2" else ")")
+                allreduce = "captured in the step's graph"
             except Exception as e:  # the collective could not be captured: keep it outside the graph
                 if rank == 0:
                     print(f"[bench] in-graph all-reduce unavailable ({type(e).__name__}: {e}); falling back", file=sys.stderr)
                 eng._collective_in_graph = False
                 mode = "graph+allreduce"
+                allreduce = "one ncclAvg over the flat gradient buffer after the graph"
                 eng.capture(x)
         else:
-            if pg is not None:
+            if rk.pg is not None:
                 mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
-            eng.capture(x)
+                allreduce = "one ncclAvg over the flat gradient buffer after the graph"
+            eng.capture(x, with_adam=args.with_adam and rk.pg is None)
 
-        def step():
+        adam_in_graph = args.with_adam and rk.pg is None
+
+        def step(i):
             eng.replay()
-            if args.with_adam:
+            if args.with_adam and not adam_in_graph:
                 eng.optimizer_step()
     else:
-        def step():
+        if rk.pg is not None:
+            allreduce = "2 buckets (decoder first), async under the encoder backward"
+
+        def step(i):
             eng.forward_backward(x)
             if args.with_adam:
                 eng.optimizer_step()
 
-    def fence():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = t.tolist()
+    wall, dev_ms = timed(rk, step, args.steps, args.warmup)
     loss = eng.loss3.detach().cpu().tolist()
 
     if rank == 0:
-        traffic = None  # L2-fill bytes per step from the committed PMC passes (profiles/, cfg2 shape only)
-        pmc = os.path.join(REPO, "profiles", "r01_cfg2_pmc.json")
-        if (D, Z, B) == (256, 64, 1024) and args.dtype == "f32" and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["hbm_bytes_per_step"]
+        traffic, traffic_source = committed_traffic(D, Z, B, args.dtype, plan)
         fpe = flop_per_embedding(D, Z) + (2 * 3 * 2 * 6 * H if args.cond else 0)  # +6 one-hot columns x3, fwd+wgrad
         peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         step_s_dev = dev_ms / 1e3 / args.steps
@@ -273,30 +473,66 @@ def main():
             "ms_per_step": round(wall / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'cfg3' if args.dtype == 'bf16' else 'cfg2'}: "
+            "config": {"workload": f"{config_label(D, Z, B, args.dtype, args.cond)}: "
                                    f"{'conditional (one-hot gender+age) ' if args.cond else ''}"
                                    f"VAE fwd+ELBO+bwd{'+Adam' if args.with_adam else ''}"
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
                                    f"batch={B}/GPU, global_batch={B * world}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
-                       "launch": mode, "parallelism": f"dp{world}", "launch_plan": plan},
+                       "launch": mode, "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
+                       "launch_plan": plan, "launches_per_step": eng.launches_per_step()},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "flop_per_embedding": fpe, "device_ms_per_step": round(step_s_dev * 1e3, 5),
                          # what `achieved` divides by: HIP-event time of the WHOLE step (every launch of it, not only
                          # the GEMM kernel -- the committed rocprofv3 summary has the per-kernel averages)
-                         "scope": "whole step: all launches of psvae_train_step (11 grouped-GEMM + weight transpose + "
-                                  "bottleneck kernel at fp32), HIP events on the launch stream"},
+                         "scope": "whole step: every launch of the training pass, HIP events on the launch stream"},
             "loss": [round(v, 6) for v in loss],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, Z, B)
         print(json.dumps(out), flush=True)
-    if use_dist:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
+    return 0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--input-dim", type=int, default=256)
+    ap.add_argument("--latent-dim", type=int, default=64)
+    ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
+    ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = config 3 arithmetic (bf16 MFMA operands, fp32 accumulate and master weights)")
+    ap.add_argument("--cond", action="store_true", help="config 3: one-hot gender+age conditioning")
+    ap.add_argument("--workload", choices=["train", "decode", "langevin"], default="train",
+                    help="train = cfg2 (headline); decode = cfg5 decode-only sampling; langevin = cfg5 conditional "
+                         "sampling (Langevin chain + decode); --samples rows in total")
+    ap.add_argument("--samples", type=int, default=1_000_000, help="decode / langevin workloads: rows over all GPUs")
+    ap.add_argument("--langevin-steps", type=int, default=100, help="Langevin steps per row (inference.py:34 default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="store_true", help="measure a launch plan now instead of using the committed one")
+    ap.add_argument("--no-tune", action="store_true", help="(kept for older command lines: tuning is opt-in now)")
+    ap.add_argument("--plan", default="", help="use this launch plan (text form printed as config.launch_plan)")
+    ap.add_argument("--stub", action="store_true", help="CPU/gloo rehearsal of the launcher and aggregation (tests)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks: give up after this many s")
+    return ap.parse_args(argv)
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_children(args)  # this process stays off the GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

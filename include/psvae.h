@@ -8,7 +8,9 @@
  *   - every buffer is caller-owned device memory (fp32, row-major, contiguous unless stated);
  *     the library allocates nothing persistent and keeps no pointer after a call returns; its only process
  *     state is the table of tuned launch plans per (B, D, Z) (psvae_tune_train_step_f32 / psvae_set_plan:
- *     small host structs, speed only) and the memo of launch-configuration choices;
+ *     small host structs, speed only) and the memo of launch-configuration choices -- both behind mutexes;
+ *     per-kernel attributes are set under std::call_once; the debug hooks are atomics: the entry points may be
+ *     called from several host threads (one stream each);
  *   - all work is enqueued on `stream`; no call synchronises the device or the host;
  *   - return 0 on success, <0 for an argument error detected before any launch, >0 = hipError_t;
  *     psvae_strerror() maps both; no C++ exception crosses the boundary;
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 1
+#define PSVAE_ABI_VERSION 2
 #define PSVAE_HIDDEN 512
 #define PSVAE_NPARAM 18
 #define PSVAE_COND_DIM 6 /* onehot3(gender) || onehot3(age), SURVEY.md section 8a row A9 */
@@ -130,17 +132,39 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
                        const psvae_grads* grads, float* g_x, void* scratch, uint32_t flags,
                        uint32_t phases, void* stream);
 
-/* One whole training pass = psvae_forward_f32 + psvae_elbo_f32 + psvae_backward_f32(elbo=1) for the
- * default loss (MSE/10 + beta*KL, no decoder normalisation), as ONE launch sequence with the elementwise
- * work folded into GEMM epilogues and one dedicated reparameterise + decoder.0 kernel (13 launches instead of
- * 19; one more when a tuned plan splits a weight gradient over workgroups).  What a Lightning step does between
- * lightning.py:67 and the end of loss.backward().  phases: PSVAE_PHASE_DECODER = forward + decoder
- * backward (decoder gradients and loss3 complete), PSVAE_PHASE_ENCODER = encoder backward. */
+/* Optional extras of psvae_train_step_f32 (a NULL struct or NULL / zero members = the defaults). */
+typedef struct psvae_step_opts {
+    /* k-major ([in, out]) copies of the 9 weight matrices in p[0], p[2], ... p[16] (the bias slots are ignored): the
+     * forward GEMMs read these (whole 128-B lines per k).  An optimizer that owns the weights keeps them current
+     * (psvae_adam_step_dev_f32 writes both layouts); NULL: the step makes the copies itself, one more launch. */
+    const psvae_params* params_kmajor;
+    const psvae_cond* cond; /* one-hot conditional tables; NULL = unconditional */
+    uint32_t flags;         /* PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS (model.py:60-61, lightning.py:110-111) */
+} psvae_step_opts;
+
+/* One whole training pass = psvae_forward_f32 + psvae_elbo_f32 + psvae_backward_f32(elbo=1) as ONE launch sequence:
+ * what a Lightning step does between lightning.py:67 and the end of loss.backward().  10 launches for the default
+ * loss when Z is a multiple of 64 (<= 128) and the k-major weight copies are supplied:
+ *   F1, F2 (+ the mu / logvar heads as a second MFMA stage on each finished tile: partial products), the forward
+ *   bottleneck kernel (sums the partials; reparameterise, KL, decoder.0), F6, F7 (+ MSE gradient and partial sums),
+ *   B1, B2 (+ decoder.0's dgrad as a second stage), the backward bottleneck kernel (g_mu, g_logvar, the heads' dgrad,
+ *   loss, Philox advance), B5, B6 (with the three Z-sized weight gradients riding along);
+ * +1 (weight transposes) without the copies, +1 (row loss kernel) for the cosine / normalised variants, +1 or 2
+ * (table gradients) with conditioning, +1 when a tuned plan splits a weight gradient over workgroups; other Z take the
+ * 12-launch sequence with separate heads / decoder.0-dgrad launches.
+ * phases: PSVAE_PHASE_DECODER = forward + decoder backward (decoder gradients and loss3 complete),
+ * PSVAE_PHASE_ENCODER = encoder backward. */
 int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
                          const float* eps_in /* nullable */, uint64_t seed, uint64_t offset,
                          uint64_t* rng_state /* nullable */, const psvae_acts* acts, float* x_hat, float* mu,
                          float* logvar, float beta, const float* grad_loss /* nullable = 1 */,
-                         const psvae_grads* grads, float* loss3, void* scratch, uint32_t phases, void* stream);
+                         const psvae_grads* grads, float* loss3, void* scratch, uint32_t phases,
+                         const psvae_step_opts* opts /* nullable */, void* stream);
+/* kernel launches the calling thread's most recent psvae_train_step_f32 issued (evidence for the launch count) */
+int psvae_last_step_launches(void);
+/* make the k-major copies of the 9 weight matrices (params_kmajor->p[2k] <- transpose of params->p[2k]); one launch */
+int psvae_transpose_params_f32(const psvae_dims* dims, const psvae_params* params, const psvae_params* params_kmajor,
+                               void* stream);
 
 /* Optional, once per (B, D, Z): time the fused step under candidate launch plans (GEMM config per launch, weight-
  * gradient split, workgroups per CU, tile order) and keep the fastest for later psvae_train_step_f32 calls in this
@@ -148,7 +172,8 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
  * grads / loss3.  Every plan computes the same result; only speed differs. */
 int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
                               const psvae_acts* acts, float* x_hat, float* mu, float* logvar,
-                              const psvae_grads* grads, float* loss3, void* scratch, int iters, void* stream);
+                              const psvae_grads* grads, float* loss3, void* scratch, int iters,
+                              const psvae_step_opts* opts /* nullable */, void* stream);
 /* text form of the plan in use for (B, D, Z) ("untuned" if none) */
 int psvae_describe_plan(const psvae_dims* dims, char* buf, size_t n);
 /* install a plan from that text form ("untuned" removes it); PSVAE_ERR_ARG if it does not parse */
@@ -216,7 +241,9 @@ int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_para
 /* LatentClassifier training step on latent rows (latent_classifier.py:7-70 as used at lightning.py:73-98):
  * logits = W1 z + b1 (hidden == 0) or W2 relu(W1 z + b1) + b2; loss2 = {mean cross entropy against y, number of rows
  * whose argmax equals the label}; g_z[B,Z] and the parameter gradients are d(mean CE)/d(.) times grad_scale
- * (overwritten).  Single-label heads with C <= 8, hidden <= 128, Z in {16, 32, 64, 128}; labels in [0, C).
+ * (overwritten).  Single-label heads with C <= 8, hidden <= 128, Z in {16, 32, 64, 128}; labels in [0, C): a row whose
+ * label is outside that range (the label maps' -1) makes the loss NaN -- the reference's F.cross_entropy raises on it,
+ * and so do the Python wrappers (latent_classifier.check_labels) before the call.
  * 3 launches (per-row kernel, loss reduction, one grouped GEMM for the weight gradients). */
 size_t psvae_classifier_scratch_bytes(int64_t B, int64_t hidden, int64_t C);
 int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, const float* z, const int64_t* y,
@@ -253,6 +280,31 @@ int psvae_gather_rows_f32(const float* table, int64_t N, int64_t D, const int64_
 int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
                         double grad_scale, void* stream);
+
+/* Adam with its step counter and learning rate ON THE DEVICE (a captured hipGraph then applies the right bias
+ * correction on every replay, and CosineAnnealingLR, lightning.py:206-213, is one 8-byte write per epoch), which also
+ * maintains the k-major weight copies psvae_step_opts::params_kmajor points at.  The flat buffers share one layout:
+ * mat_off/rows/cols = the 9 weight matrices ([rows, cols] = [out, in]) inside them, the k-major copy of matrix k lives
+ * at the same offset of param_kmajor as [cols, rows]; vec_off/len = every other trained range (biases, conditional
+ * tables).  *state must be zero-initialised except lr.  One launch. */
+typedef struct psvae_adam_state {
+    double lr;
+    int64_t step;   /* completed optimizer steps; advanced by the kernel */
+    uint32_t ticket; /* internal (0 between launches) */
+    uint32_t pad;
+} psvae_adam_state;
+typedef struct psvae_adam_dev {
+    float* param;
+    float* param_kmajor; /* nullable */
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t mat_off[9], mat_rows[9], mat_cols[9];
+    int64_t vec_off[16], vec_len[16];
+    int32_t n_vec;
+} psvae_adam_dev;
+int psvae_adam_step_dev_f32(const psvae_adam_dev* layout, psvae_adam_state* state /* device */, double beta1,
+                            double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -413,15 +413,15 @@ def classifier_ce(layers, z, y):
     return loss.detach(), hits, zz.grad, [(W.grad, b.grad) for W, b in ps]
 
 
-def train_step_with_classifier(p, layers, x, y, eps, beta: float = 1.0, cw: float = 1.0):
+def train_step_with_classifier(p, layers, x, y, eps, beta: float = 1.0, cw: float = 1.0, masks=None):
     """lightning.py:67-131 with a single-label LatentClassifier head on mu: total = recon + beta*kl + cw*CE.
     Returns dict(total, recon, kl, ce, hits), the 18 VAE gradients and [(dW, db), ...] of the classifier."""
     acts = forward(p, x, eps, False)
     recon, kl, total = elbo(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False)
     ce, hits, g_mu_cls, cgrads = classifier_ce(layers, acts["mu"], y)
     g_xh, g_mu_d, g_lv_d = elbo_grads(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False, 1.0)
-    grads, _ = backward(p, x, acts, g_xh, g_mu_d + cw * g_mu_cls, g_lv_d, False)
-    return (dict(total=total + cw * ce, recon=recon, kl=kl, ce=ce, hits=hits), grads,
+    grads, _ = backward(p, x, acts, g_xh, g_mu_d + cw * g_mu_cls, g_lv_d, False, masks=masks)
+    return (dict(total=total + cw * ce, recon=recon, kl=kl, ce=ce, hits=hits, acts=acts), grads,
             [(cw * gW, cw * gb) for gW, gb in cgrads])
 
 

@@ -21,7 +21,7 @@ COND_DIM = 6
 NORMALIZE_DECODER = 1
 COS_LOSS = 2
 PHASE_DECODER, PHASE_ENCODER, PHASE_ALL = 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
@@ -31,6 +31,7 @@ SYMBOLS = (
     "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_consistency_scratch_bytes", "psvae_consistency_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
+    "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32",
 )
 
 
@@ -48,6 +49,21 @@ class Grads(C.Structure):
 
 class Cond(C.Structure):
     _fields_ = [("tab", C.c_void_p * 3), ("gtab", C.c_void_p * 3), ("gender", C.c_void_p), ("age", C.c_void_p)]
+
+
+class StepOpts(C.Structure):
+    _fields_ = [("params_kmajor", C.POINTER(Params)), ("cond", C.POINTER(Cond)), ("flags", C.c_uint32)]
+
+
+class AdamState(C.Structure):  # device-resident: lr, completed steps, the kernel's ticket
+    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("ticket", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class AdamDev(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("param_kmajor", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("mat_off", C.c_int64 * 9), ("mat_rows", C.c_int64 * 9),
+                ("mat_cols", C.c_int64 * 9), ("vec_off", C.c_int64 * 16), ("vec_len", C.c_int64 * 16),
+                ("n_vec", C.c_int32)]
 
 
 class Mlp3Grads(C.Structure):
@@ -93,14 +109,21 @@ def lib() -> C.CDLL:
     L.psvae_backward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), C.POINTER(Acts),
                                      vp, vp, vp, vp, vp, vp, C.c_int, f32, vp, C.POINTER(Grads), vp, vp, u32, u32, vp]
     L.psvae_tune_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Acts), vp, vp, vp,
-                                            C.POINTER(Grads), vp, vp, C.c_int, vp]
+                                            C.POINTER(Grads), vp, vp, C.c_int, C.POINTER(StepOpts), vp]
     L.psvae_tune_train_step_f32.restype = C.c_int
     L.psvae_describe_plan.argtypes = [C.POINTER(Dims), C.c_char_p, C.c_size_t]
     L.psvae_describe_plan.restype = C.c_int
     L.psvae_set_plan.argtypes = [C.POINTER(Dims), C.c_char_p]
     L.psvae_set_plan.restype = C.c_int
     L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
-                                       vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
+                                       vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, C.POINTER(StepOpts), vp]
+    L.psvae_last_step_launches.restype = C.c_int
+    L.psvae_last_step_launches.argtypes = []
+    L.psvae_transpose_params_f32.argtypes = [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), vp]
+    L.psvae_transpose_params_f32.restype = C.c_int
+    L.psvae_adam_step_dev_f32.argtypes = [C.POINTER(AdamDev), vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, vp]
+    L.psvae_adam_step_dev_f32.restype = C.c_int
     L.psvae_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_bf16_scratch_bytes.argtypes = [C.POINTER(Dims)]
     L.psvae_train_step_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), vp, u64, u64, vp, vp,
@@ -173,6 +196,16 @@ def make_params(tensors: Sequence[torch.Tensor]) -> Params:
             raise PsvaeError("parameters must be float32")
         p.p[i] = ptr(t)
     return p
+
+
+def make_step_opts(params_kmajor: Optional[Params] = None, cond: Optional["Cond"] = None, flags: int = 0):
+    """psvae_step_opts for psvae_train_step_f32; the returned object keeps its members alive"""
+    o = StepOpts()
+    o._keep = (params_kmajor, cond)
+    o.params_kmajor = C.pointer(params_kmajor) if params_kmajor is not None else None
+    o.cond = C.pointer(cond) if cond is not None else None
+    o.flags = int(flags)
+    return o
 
 
 def make_grads(tensors: Sequence[torch.Tensor]) -> Grads:

@@ -98,7 +98,11 @@ __global__ __launch_bounds__(256) void classifier_ce_kernel(int64_t B, int hidde
 #pragma unroll
     for (int c = 0; c < CL_MAXC; ++c)
         if (c == label) ly = logits[c];
-    const float loss_row = live ? (mx + logf(den)) - ly : 0.f;
+    // a label outside [0, C) (e.g. the -1 "unknown" of the label maps, utils.py:103,120,136) has no class to score: the
+    // reference's F.cross_entropy raises on it.  Here the row's loss term becomes NaN, so the step's loss is visibly
+    // poisoned without a host round trip; the Python wrappers additionally check the labels and raise (PSVAE_CHECK_LABELS)
+    const bool bad_label = live && (label < 0 || label >= C);
+    const float loss_row = live ? (bad_label ? __builtin_nanf("") : (mx + logf(den)) - ly) : 0.f;
     const float hit_row = (live && arg == label) ? 1.f : 0.f;
 #pragma unroll
     for (int c = 0; c < CL_MAXC; ++c) {

@@ -6,6 +6,7 @@
 #include <hip/hip_bf16.h>
 
 #include "psvae_common.h"
+#include "psvae_device.h"
 
 namespace psvae {
 
@@ -26,38 +27,6 @@ __device__ __forceinline__ void emit_bf16(const Bf16Out& o, int which, int64_t i
     const int64_t row = i / o.Z, col = i - row * o.Z;
     o.rm[which][i] = b;
     o.tr[which][col * (int64_t)o.Bp + row] = b;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011).  One lane = one Philox block = 4 normals for 4 consecutive
-// elements, so a wavefront covers 256 contiguous elements and stores 16 B per lane.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&out)[4]) {
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += W0; k1 += W1;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ f32x4 philox_normal4(uint64_t blk, uint64_t seed) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    constexpr float S = 5.9604644775390625e-08f;  // 2^-24
-    const float u0 = ((float)(r[0] >> 8) + 0.5f) * S, u1 = ((float)(r[1] >> 8) + 0.5f) * S;
-    const float u2 = ((float)(r[2] >> 8) + 0.5f) * S, u3 = ((float)(r[3] >> 8) + 0.5f) * S;
-    constexpr float TWO_PI = 6.283185307179586f;
-    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-    float sa, ca, sb, cb;
-    sincosf(TWO_PI * u1, &sa, &ca);
-    sincosf(TWO_PI * u3, &sb, &cb);
-    return f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
 }
 
 __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
@@ -86,23 +55,6 @@ hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t o
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, out, n, seed, offset);
     return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// wave helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// fixed-order sum over the 256 threads of a block; result valid in thread 0
-__device__ __forceinline__ float block_sum_256(float v, float* sh4) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
 }
 
 // fused-step reparameterisation: z = mu + exp(0.5 lv) * eps, plus one KL partial per block
@@ -155,117 +107,6 @@ __global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict
     }
     const float s = block_sum_256(kl, sh4);
     if (threadIdx.x == 0) kl_partials[blockIdx.x] = s;
-}
-
-// Fused-step "bottleneck": reparameterisation + KL partial sums + decoder layer 0 in ONE launch
-//   eps, z = mu + exp(0.5 lv) eps   (model.py:56-57);   d1 = relu(z Wd1^T + b)   (model.py:30-31,58)
-// The layer has K = Z = 64: its GEMM launch and the elementwise launch in front of it were both at the launch
-// floor.  A workgroup owns 16 rows x 128 columns: every workgroup recomputes its 16 x Z slice of z (one Philox
-// block per lane: the same counter layout as reparam_kl_kernel, so eps is bit-identical), keeps it in LDS as the A
-// operand, and the 4 waves multiply it with 32 columns of Wd1 each (fragments straight from global: the weight rows
-// are 4Z contiguous bytes).  The column-0 workgroups also write eps and z and one KL partial per row tile.
-// Needs Z % 16 == 0 and N % 4 == 0; anything else takes the separate kernels.
-template <int MAXC>  // Z <= 16 * MAXC
-__global__ __launch_bounds__(256) void reparam_linear_kernel(
-    const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps_in,
-    const uint64_t* __restrict__ rng, uint64_t seed, uint64_t offset, const float* __restrict__ W,
-    const float* __restrict__ bias, float* __restrict__ eps_out, float* __restrict__ z_out, float* __restrict__ Y,
-    float* __restrict__ kl_partials, int B, int Z, int N) {
-    constexpr int ZS = 16 * MAXC + 4;  // LDS row stride of the z tile
-    constexpr int OS = 128 + 4;        // ... of the output tile
-    __shared__ __attribute__((aligned(16))) float zs[16 * ZS];
-    __shared__ __attribute__((aligned(16))) float os[16 * OS];
-    __shared__ float sh4[4];
-    if (rng) { seed = rng[0]; offset = rng[1]; }
-    const int tiles_n = (N + 127) / 128;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
-    const int m0 = tm * 16, n0 = tn * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    // ---- 0. this wave's weight fragments: issued first, they land while z is being made ----
-    const int nc = Z >> 4;
-    f32x4 wf[MAXC][2];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + 32 * wave + 16 * b + r;
-            n = n < N ? n : N - 1;  // clamped columns are never stored
-            wf[c][b] = (c < nc) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * Z + 16 * c + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    // ---- 1. the 16 x Z slice of z (float4 = one Philox block), KL terms ----
-    float kl = 0.f;
-    const int zq = Z >> 2;  // float4 per row
-    for (int i = tid; i < 16 * zq; i += 256) {
-        const int row = i / zq, col = 4 * (i - row * zq);
-        f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + row < B) {
-            const int64_t e = (int64_t)(m0 + row) * Z + col;
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mu + e);
-            const f32x4 l = *reinterpret_cast<const f32x4*>(lv + e);
-            const f32x4 ep = eps_in ? *reinterpret_cast<const f32x4*>(eps_in + e) : philox_normal4(offset + (uint64_t)(e >> 2), seed);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                zz[t] = m[t] + expf(0.5f * l[t]) * ep[t];
-                kl += 1.0f + l[t] - m[t] * m[t] - expf(l[t]);
-            }
-            if (tn == 0) {
-                *reinterpret_cast<f32x4*>(eps_out + e) = ep;
-                *reinterpret_cast<f32x4*>(z_out + e) = zz;
-            }
-        }
-        *reinterpret_cast<f32x4*>(zs + row * ZS + col) = zz;
-    }
-    const float kls = block_sum_256(kl, sh4);  // (contains the barrier that publishes zs)
-    if (tn == 0 && tid == 0) kl_partials[tm] = kls;
-    // ---- 2. 16 x 128 tile of z Wd1^T: wave w owns columns n0 + 32 w .. + 31 ----
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < nc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(zs + r * ZS + 16 * c + 4 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], wf[c][b][t], acc[b], 0, 0, 0);
-        }
-    }
-    // ---- 3. whole rows leave through LDS: + bias, ReLU ----
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) os[(4 * q + j) * OS + 32 * wave + 16 * b + r] = acc[b][j];
-    __syncthreads();
-    for (int i = tid; i < 16 * 32; i += 256) {
-        const int row = i >> 5, c4 = i & 31;
-        const int col = n0 + 4 * c4;
-        if (m0 + row >= B || col >= N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(os + row * OS + 4 * c4);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);  // N % 4 == 0
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t] + bb[t], 0.f);
-        *reinterpret_cast<f32x4*>(Y + (size_t)(m0 + row) * N + col) = v;
-    }
-}
-
-bool reparam_linear_ok(int Z, int N, const void* const* ptrs, int nptr) {
-    if ((Z & 15) || Z > 128 || (N & 3)) return false;
-    for (int i = 0; i < nptr; ++i)
-        if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
-    return true;
-}
-int reparam_linear_tiles(int B) { return (B + 15) / 16; }
-hipError_t launch_reparam_linear(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
-                                 uint64_t seed, uint64_t offset, const float* W, const float* bias, float* eps_out,
-                                 float* z_out, float* Y, float* kl_partials, int B, int Z, int N, hipStream_t s) {
-    if (eps_in) rng = nullptr;
-    const int grid = reparam_linear_tiles(B) * ((N + 127) / 128);
-    if (Z <= 64)
-        hipLaunchKernelGGL(reparam_linear_kernel<4>, dim3(grid), dim3(256), 0, s, mu, lv, eps_in, rng, seed, offset, W, bias,
-                           eps_out, z_out, Y, kl_partials, B, Z, N);
-    else
-        hipLaunchKernelGGL(reparam_linear_kernel<8>, dim3(grid), dim3(256), 0, s, mu, lv, eps_in, rng, seed, offset, W, bias,
-                           eps_out, z_out, Y, kl_partials, B, Z, N);
-    return hipGetLastError();
 }
 
 // z = mu + exp(0.5 lv) * eps     (model.py:56-57)

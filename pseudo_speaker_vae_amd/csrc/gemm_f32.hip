@@ -22,6 +22,7 @@
 //   * bias gradients (column sums of dY) come from the A fragments already in registers.
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "psvae_common.h"
@@ -101,7 +102,7 @@ __device__ __forceinline__ void load_frag(float (&f)[4][T], const float* __restr
 template <int T, bool KM>
 __device__ __forceinline__ int slot_index(int blk, int slot) { return KM ? T * slot + blk : 16 * blk + slot; }
 
-template <int TM, int TN, int WM, int WN, int KS, int D, bool AKM, bool BKM>
+template <int TM, int TN, int WM, int WN, int KS, int D, bool AKM, bool BKM, bool S2 = false>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     constexpr int NW = WM * WN * KS;  // waves per workgroup: 4 or 8
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -363,6 +364,46 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             for (int e = 0; e < 4; ++e)
                 if (col + e < N) stg<float>(C + o + e, v[e]);
         }
+        if (S2) *reinterpret_cast<f32x4*>(smem + lr * SC + 4 * c4) = v;  // the finished tile stays in LDS for stage 2
+    }
+    if (S2) {
+        // ---- second stage: slab2[tn][row][:] = T[row][0..BN) * B2[n0.., :] (see GemmDesc::B2).  Wave w owns tile rows
+        // 16w..16w+15; A fragments come from LDS (4 consecutive k per lane, as the "KC" operand of the main loop), B
+        // fragments straight from global (k-major rows of Z2 floats, 16 B per lane).  Only compiled into the dedicated
+        // <.., 6> instantiations, so the generic kernels stay as small as they were.
+        static_assert(!S2 || (WM == 1 && WN == 1 && KS == 4 && TM == 4 && TN == 4), "stage 2 is written for config 6");
+        __syncthreads();
+        if (d.B2 != nullptr) {
+            const int Z2 = d.Z2;
+            const float* __restrict__ W2 = d.B2 + (size_t)n0 * Z2;
+            float* __restrict__ slab = d.slab2 + (size_t)tn * M * Z2;
+            for (int zc = 0; zc < Z2; zc += 64) {
+                f32x4 a4[4], b4[4][4];
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b4[c2][t] = ldg<f32x4>(W2 + (size_t)(16 * c2 + 4 * q + t) * Z2 + zc + 4 * r);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) a4[c2] = *reinterpret_cast<const f32x4*>(smem + (16 * wave + r) * SC + 16 * c2 + 4 * q);
+                f32x4 acc2[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c2][t], b4[c2][t][n], acc2[n], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = m0 + 16 * wave + 4 * q + j;
+                    if (row < M)
+                        stg<f32x4>(slab + (size_t)row * Z2 + zc + 4 * r, f32x4{acc2[0][j], acc2[1][j], acc2[2][j], acc2[3][j]});
+                }
+            }
+        }
+        __syncthreads();
     }
     if (epi == EPI_BIAS_RECON) {  // fixed-order block sum of the squared errors -> one partial per tile
         float* __restrict__ red = smem + KS * (BM * SC) + KS * BM;  // 4 floats past the csum area
@@ -395,7 +436,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             float kt = 0.f, rt = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) { kt += red[w]; rt += red[NW + w]; }
-            const float recon = rt / ((float)M * (float)d.loss_D) / 10.0f;
+            const float recon = d.loss_D < 0 ? rt / (float)M : rt / ((float)M * (float)d.loss_D) / 10.0f;
             const float kl = -0.5f * kt / (float)M;
             stg<float>(d.loss3, recon + d.scale * kl);
             stg<float>(d.loss3 + 1, recon);
@@ -446,9 +487,13 @@ static const Cfg kCfgs[NCFG] = {
     {4, 4, 2, 2, 1, 2, 0.92f, false}, {1, 2, 1, 1, 4, 4, 0.62f, true},  {4, 4, 1, 2, 2, 2, 0.92f, false},
 };
 
-template <int ID>
+template <int ID, bool S2 = false>
 __device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, int ksg, float* __restrict__ smem) {
     typedef CfgT<ID> C;
+    if (S2) {  // the stage-2 launches of the fused step are forward (k-major weights) or dgrad problems: NN only
+        if (d.kind == GK_NN) gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, true, S2>(d, tm, tn, ksg, smem);
+        return;
+    }
     if (d.kind == GK_NT)
         gemm_tile<C::TM, C::TN, C::WM, C::WN, C::KS, C::D, false, false>(d, tm, tn, ksg, smem);
     else if (d.kind == GK_NN)
@@ -461,7 +506,7 @@ __device__ __forceinline__ void run_cfg(const GemmDesc& d, int tm, int tn, int k
 // tiles, deep k split), everything else runs C1 (wide tiles): workgroups of both shapes share the
 // machine and fill each other's bubbles.  (One kernel holding all nine configs made hipcc park the
 // fragment arrays in scratch; pairs compile clean.)
-template <int C0, int C1>
+template <int C0, int C1, bool S2 = false>
 __global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) void gemm_grouped_kernel(const GemmBatch batch) {
     static_assert(CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS == CfgT<C1>::WM * CfgT<C1>::WN * CfgT<C1>::KS,
                   "both configs of a launch need the same workgroup size");
@@ -484,10 +529,16 @@ __global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) vo
     const int ksg = lt / tiles_mn;  // cross-workgroup k slice (0 when ksplit == 1)
     lt -= ksg * tiles_mn;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    if (C0 == C1 || d.cfg == C0)
+    if (S2) {  // weight gradients (TN) run C0, every other problem is a config-6 tile with the second stage
+        if (d.kind == GK_TN)
+            run_cfg<C0>(d, tm, tn, ksg, smem);
+        else
+            run_cfg<C1, S2>(d, tm, tn, ksg, smem);
+    } else if (C0 == C1 || d.cfg == C0) {
         run_cfg<C0>(d, tm, tn, ksg, smem);
-    else
+    } else {
         run_cfg<C1>(d, tm, tn, ksg, smem);
+    }
 }
 
 // Persistent variant for decode-sized launches of ONE config without weight-gradient problems: one workgroup per CU
@@ -510,13 +561,13 @@ __global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) vo
 
 template <int C0>
 static hipError_t launch_persistent(const GemmBatch& b, size_t lds, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<C0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<C0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     constexpr int NT = 64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS;
     hipLaunchKernelGGL((gemm_persistent_kernel<C0>), dim3(256), dim3(NT), lds, stream, b);
     return hipGetLastError();
@@ -527,8 +578,8 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int g_forced = -1;  // -1: read PSVAE_TILE once; the tuning hook psvae_debug_force_tile overrides
-void debug_force_tile(int cfg) { g_forced = cfg; }
+static std::atomic<int> g_forced{-1};  // -1: PSVAE_TILE (read once); the tuning hook psvae_debug_force_tile overrides
+void debug_force_tile(int cfg) { g_forced.store(cfg); }
 int num_gemm_configs() { return NCFG; }
 
 // Cost model (cycles), fitted to rocprofv3 sweeps and tools/gemm_bench.py.  One workgroup of config c on problem d:
@@ -601,8 +652,9 @@ static const int kOtherCands[] = {1, 2, 4, 6, 8, 7, 9};  // forward / dgrad; 7 a
 
 // cfg == 0: choose one config for the TN problems and one for the others; else force `cfg` everywhere
 void finalize_batch(GemmBatch& b, int cfg) {
-    if (g_forced < 0) g_forced = env_int("PSVAE_TILE", 0);
-    if (cfg == 0 && g_forced > 0 && g_forced <= NCFG) cfg = g_forced;
+    static const int env_tile = env_int("PSVAE_TILE", 0);
+    const int forced = g_forced.load() < 0 ? env_tile : g_forced.load();
+    if (cfg == 0 && forced > 0 && forced <= NCFG) cfg = forced;
     int pick_tn = cfg, pick_other = cfg;
     static const int force_tn = env_int("PSVAE_CFG_TN", 0), force_other = env_int("PSVAE_CFG_OTHER", 0);  // tuning
     if (cfg == 0) {
@@ -659,6 +711,11 @@ void finalize_batch(GemmBatch& b, int cfg) {
         if (b.hint_tn > 0 && b.hint_tn <= NCFG) pick_tn = b.hint_tn;  // a tuned plan wins
         if (b.hint_other > 0 && b.hint_other <= NCFG) pick_other = b.hint_other;
     }
+    for (int i = 0; i < b.n; ++i)
+        if (b.d[i].B2 != nullptr) {  // the second stage exists for config 6 only, beside weight gradients in 1, 2, 6 or 8
+            pick_other = 6;
+            if (pick_tn != 1 && pick_tn != 2 && pick_tn != 6 && pick_tn != 8) pick_tn = 2;
+        }
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
         GemmDesc& d = b.d[i];
@@ -682,17 +739,19 @@ static size_t lds_bytes(const Cfg& c) {
     return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 16) * sizeof(float);
 }
 
-template <int C0, int C1>
+// the dynamic-LDS limit of a kernel is raised once per process; std::call_once makes that safe from any thread
+// (the library keeps no other mutable state per kernel: SURVEY 8b threading contract)
+template <int C0, int C1, bool S2 = false>
 static hipError_t launch_pair(const GemmBatch& b, size_t lds, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {  // (the limit is set once, to the most any config or PSVAE_LDS_MIN asks)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1, S2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     constexpr int NT = 64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS;
-    hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1>), dim3(b.total_tiles), dim3(NT), lds, stream, b);
+    hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1, S2>), dim3(b.total_tiles), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 
@@ -727,6 +786,23 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
             if (c0 == 7) return launch_persistent<7>(b, lds, stream);
             if (c0 == 6) return launch_persistent<6>(b, lds, stream);
         }
+    }
+    bool stage2 = false;
+    for (int i = 0; i < b.n; ++i) stage2 = stage2 || b.d[i].B2 != nullptr;
+    if (stage2) {
+        for (int i = 0; i < b.n; ++i) {
+            const GemmDesc& d = b.d[i];
+            if (d.kind == GK_TN) continue;
+            if (d.cfg != 6 || d.kind != GK_NN || d.B2 == nullptr || d.slab2 == nullptr || (d.N & 63) || (d.Z2 & 63) ||
+                d.Z2 <= 0 || d.ksplit != 1 || (reinterpret_cast<uintptr_t>(d.B2) & 15) ||
+                (reinterpret_cast<uintptr_t>(d.slab2) & 15))
+                return hipErrorInvalidValue;
+        }
+        if (c0 == 6) return launch_pair<6, 6, true>(b, lds, stream);
+        if (c0 == 1) return launch_pair<1, 6, true>(b, lds, stream);
+        if (c0 == 2) return launch_pair<2, 6, true>(b, lds, stream);
+        if (c0 == 8) return launch_pair<8, 6, true>(b, lds, stream);
+        return hipErrorInvalidValue;
     }
 #define PSVAE_PAIR(A, B) if (c0 == A && c1 == B) return launch_pair<A, B>(b, lds, stream)
     PSVAE_PAIR(1, 1); PSVAE_PAIR(2, 2); PSVAE_PAIR(3, 3); PSVAE_PAIR(4, 4); PSVAE_PAIR(5, 5);

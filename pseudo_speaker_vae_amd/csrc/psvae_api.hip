@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -29,10 +30,10 @@ int check_dims(const psvae_dims* d) {
 // tiles at the same workgroup count (half the traffic); the S partial tiles go to slabs that one
 // slab_reduce launch per phase sums in fixed order (bitwise reproducible, no atomics).
 constexpr int WGRAD_SMAX = 4;
-int g_wgrad_forced = -1;  // -1: read PSVAE_WGRAD_S once; psvae_debug_force_wgrad_split overrides (0 = automatic)
+std::atomic<int> g_wgrad_forced{-1};  // -1: PSVAE_WGRAD_S (read once); psvae_debug_force_wgrad_split overrides (0 = automatic)
 inline int wgrad_ksplit(int64_t B) {
-    if (g_wgrad_forced < 0) g_wgrad_forced = getenv("PSVAE_WGRAD_S") ? atoi(getenv("PSVAE_WGRAD_S")) : 0;
-    const int forced = g_wgrad_forced;
+    static const int env_s = getenv("PSVAE_WGRAD_S") ? atoi(getenv("PSVAE_WGRAD_S")) : 0;
+    const int forced = g_wgrad_forced.load() < 0 ? env_s : g_wgrad_forced.load();
     if (forced >= 1 && forced <= WGRAD_SMAX) return forced;
     (void)B;
     return 1;  // untuned default: no split (the tuner enables it per launch where the whole step gets faster)
@@ -44,6 +45,7 @@ struct Scratch {
     float* wt[9];  // k-major ([in,out]) copies of the 9 weight matrices for the fused step's forward
     float* slab_w[9];  // cross-workgroup split-K partials of the 9 weight gradients, [WGRAD_SMAX][out*in]
     float* slab_b[9];  // ... and of the 9 bias gradients, [WGRAD_SMAX][out]
+    float *slab_mu, *slab_lv, *slab_gz;  // second-stage partial products [STAGE2_SLABS][B][Z] (fused step, Z % 64 == 0)
     int n_recon_max;
     size_t bytes;
 };
@@ -73,6 +75,7 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
         s.kl_partials = take(blocks > tiles ? blocks : tiles);
     }
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));  // smallest GEMM tile is 16 x 32
+    if (s.n_recon_max < recon_row_blocks((int)B)) s.n_recon_max = recon_row_blocks((int)B);  // row-kernel variants
     s.recon_partials = take((size_t)s.n_recon_max);
     {
         const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
@@ -80,6 +83,9 @@ Scratch carve(void* base, int64_t B, int64_t D, int64_t Z) {
         for (int k = 0; k < 9; ++k) s.slab_w[k] = take((size_t)(WGRAD_SMAX * o[k] * in[k]));
         for (int k = 0; k < 9; ++k) s.slab_b[k] = take((size_t)(WGRAD_SMAX * o[k]));
     }
+    s.slab_mu = take((size_t)8 * B * Z);  // STAGE2_SLABS = H / 64
+    s.slab_lv = take((size_t)8 * B * Z);
+    s.slab_gz = take((size_t)8 * B * Z);
     s.bytes = off;
     return s;
 }
@@ -132,11 +138,13 @@ inline void set_cond(GemmDesc& d, const psvae_cond* c, int which) {
 // graph is being captured: the captured launches carry the tuned configs).
 std::mutex g_plan_mu;
 std::map<std::tuple<int64_t, int64_t, int64_t>, StepPlan> g_plans;
-const StepPlan* g_trial = nullptr;  // the tuner's candidate (single-threaded use under g_tune_mu)
+thread_local const StepPlan* t_trial = nullptr;  // the tuner's candidate: seen only by the tuning thread's own calls
 std::mutex g_tune_mu;
+thread_local int t_launches = 0;       // launches issued by this thread's current / last psvae_train_step_f32
+constexpr int STAGE2_SLABS = H / 64;   // partial products per row tile when a 512-wide layer is cut in 64-column tiles
 
 bool find_plan(int64_t B, int64_t D, int64_t Z, StepPlan* out) {
-    if (g_trial) { *out = *g_trial; return true; }
+    if (t_trial) { *out = *t_trial; return true; }
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto it = g_plans.find(std::make_tuple(B, D, Z));
     if (it == g_plans.end()) return false;
@@ -163,7 +171,7 @@ int psvae_debug_force_tile(int tile) {
 
 int psvae_debug_force_wgrad_split(int s) {
     if (s < 0 || s > WGRAD_SMAX) return PSVAE_ERR_ARG;
-    g_wgrad_forced = s;
+    g_wgrad_forced.store(s);
     return 0;
 }
 
@@ -393,15 +401,20 @@ int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_param
     return 0;
 }
 
-// forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs:
-//   reparam also emits KL partial sums; the last decoder GEMM's epilogue also writes the MSE gradient and
-//   MSE partial sums; the reparam-backward kernel also finishes the loss and advances the Philox state.
-// 13 launches (+1 when a weight gradient is split over workgroups) instead of 19.  Only for the default loss
-// (MSE/10, no decoder normalisation).
+// forward + ELBO + backward as ONE launch sequence with the elementwise work folded into the GEMMs and the two
+// skinny layers next to the bottleneck folded into their neighbours (see include/psvae.h for the launch list):
+//   * the mu / logvar heads ride on encoder layer 1's launch as a second MFMA stage per finished tile (partial products,
+//     summed in fixed order by the forward bottleneck kernel, which also reparameterises, sums KL and runs decoder.0);
+//   * decoder.0's dgrad rides on decoder.2's dgrad launch the same way; the backward bottleneck kernel sums the partials,
+//     turns g_z into g_mu / g_logvar, runs the heads' dgrad (K = Z), finishes the loss and advances the Philox state;
+//   * the last decoder GEMM's epilogue writes the MSE gradient and MSE partial sums (default loss), or one row kernel
+//     does normalisation + loss term + gradient (cosine / normalised variants);
+//   * the three Z-sized weight gradients ride on the last launch.
 int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const float* eps_in,
                          uint64_t seed, uint64_t offset, uint64_t* rng_state, const psvae_acts* acts, float* x_hat,
                          float* mu, float* logvar, float beta, const float* grad_loss, const psvae_grads* grads,
-                         float* loss3, void* scratch, uint32_t phases, void* stream) {
+                         float* loss3, void* scratch, uint32_t phases, const psvae_step_opts* opts, void* stream) {
+    t_launches = 0;
     if (int e = check_dims(dims)) return e;
     if (!x || !params || !acts || !x_hat || !mu || !logvar || !grads || !loss3 || !scratch) return PSVAE_ERR_NULL;
     if (phases == 0 || (phases & ~PSVAE_PHASE_ALL)) return PSVAE_ERR_ARG;
@@ -409,6 +422,19 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         if (!params->p[i] || !grads->g[i]) return PSVAE_ERR_NULL;
     if (!acts->h1m || !acts->h2m || !acts->h1s || !acts->h2s || !acts->eps || !acts->z || !acts->d1 || !acts->d2)
         return PSVAE_ERR_NULL;
+    const uint32_t flags = opts ? opts->flags : 0u;
+    if (flags & ~(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS)) return PSVAE_ERR_ARG;
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER, cos_loss = flags & PSVAE_COS_LOSS;
+    const bool variant = flags != 0;
+    if (normalize && !acts->ynorm) return PSVAE_ERR_NULL;
+    const psvae_cond* cond = (opts && opts->cond && opts->cond->tab[0]) ? opts->cond : nullptr;
+    if (cond && (!cond->gender || !cond->age || !cond->tab[1] || !cond->tab[2] || !cond->gtab[0] || !cond->gtab[1] ||
+                 !cond->gtab[2]))
+        return PSVAE_ERR_NULL;
+    const psvae_params* km = opts ? opts->params_kmajor : nullptr;
+    if (km)
+        for (int k = 0; k < 9; ++k)
+            if (!km->p[2 * k]) return PSVAE_ERR_NULL;
     const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
     hipStream_t s = (hipStream_t)stream;
     const float* const* P = params->p;
@@ -418,11 +444,20 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     StepPlan plan{};
     find_plan(B, D, Z, &plan);  // all-zero (heuristics) when this shape was never tuned
 
+#define LAUNCH(e)                             \
+    do {                                      \
+        hipError_t _e = (e);                  \
+        if (_e != hipSuccess) return (int)_e; \
+        ++t_launches;                         \
+    } while (0)
+
     static const bool kmajor_w = getenv("PSVAE_FWD_NT") == nullptr;  // default: forward reads k-major weight copies
+    const float* WT[9];
+    for (int k = 0; k < 9; ++k) WT[k] = km ? km->p[2 * k] : sc.wt[k];
     // forward Linear l:  Y = X W^T.  With the k-major copy WT[in,out] it is the NN product X * WT, whose weight
     // operand is read in whole 128-B lines (the k-contiguous W[out,in] is read in half lines).
     auto fwd = [&](const float* X, int K, int wk, int N, float* Y, int epi) {
-        return kmajor_w ? make_desc(GK_NN, B, N, K, X, K, sc.wt[wk], N, Y, N, epi, P[2 * wk + 1])
+        return kmajor_w ? make_desc(GK_NN, B, N, K, X, K, WT[wk], N, Y, N, epi, P[2 * wk + 1])
                         : make_desc(GK_NT, B, N, K, X, K, P[2 * wk], K, Y, N, epi, P[2 * wk + 1]);
     };
     auto launch = [&](GemmBatch& b, int site) {
@@ -436,52 +471,73 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         wg.S = (S >= 1 && S <= WGRAD_SMAX) ? S : S_default;
         return wg.desc(k, M, N, dY, X);
     };
+    // the second-stage fusion needs the k-major copies, Z in whole 64-column groups and 16-B aligned operands
+    const void* al[] = {mu, logvar, eps_in, acts->eps, acts->z, acts->d1, P[12], P[13], P[5], P[11], sc.gmu, sc.glv,
+                        acts->h2m, acts->h2s};
+    const bool bn_ok = reparam_linear_ok(Z, H, al, 14);
+    static const bool stage2_on = getenv("PSVAE_NO_STAGE2") == nullptr;
+    static const bool bottleneck_on = getenv("PSVAE_NO_BOTTLENECK") == nullptr;
+    const bool fuse = stage2_on && bottleneck_on && kmajor_w && bn_ok && (Z & 63) == 0 && Z <= 128;
+    const bool all = phases == PSVAE_PHASE_ALL;
+
     if (phases & PSVAE_PHASE_DECODER) {
-        if (kmajor_w) {
+        if (kmajor_w && !km) {
             const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
             const float* src[9]; int R[9], C[9];
             for (int k = 0; k < 9; ++k) { src[k] = P[2 * k]; R[k] = (int)o[k]; C[k] = (int)in[k]; }
-            RET_IF(launch_transpose_f32(src, sc.wt, R, C, 9, s));
+            LAUNCH(launch_transpose_f32(src, sc.wt, R, C, 9, s));
         }
         {
             GemmBatch b{};
-            add(b, fwd(x, D, 0, H, acts->h1m, EPI_BIAS_RELU));
-            add(b, fwd(x, D, 3, H, acts->h1s, EPI_BIAS_RELU));
-            RET_IF(launch(b, 0));
+            GemmDesc dm = fwd(x, D, 0, H, acts->h1m, EPI_BIAS_RELU), ds = fwd(x, D, 3, H, acts->h1s, EPI_BIAS_RELU);
+            set_cond(dm, cond, 0);
+            set_cond(ds, cond, 1);
+            add(b, dm); add(b, ds);
+            LAUNCH(launch(b, 0));
         }
         {
             GemmBatch b{};
-            add(b, fwd(acts->h1m, H, 1, H, acts->h2m, EPI_BIAS_RELU));
-            add(b, fwd(acts->h1s, H, 4, H, acts->h2s, EPI_BIAS_RELU));
-            RET_IF(launch(b, 1));
+            GemmDesc dm = fwd(acts->h1m, H, 1, H, acts->h2m, EPI_BIAS_RELU), ds = fwd(acts->h1s, H, 4, H, acts->h2s, EPI_BIAS_RELU);
+            if (fuse) {  // heads: slab[tn] = relu-tile(h2) * W3^T rows of that tile
+                dm.B2 = WT[2]; dm.slab2 = sc.slab_mu; dm.Z2 = Z;
+                ds.B2 = WT[5]; ds.slab2 = sc.slab_lv; ds.Z2 = Z;
+            }
+            add(b, dm); add(b, ds);
+            LAUNCH(launch(b, 1));
         }
-        {
+        if (!fuse) {
             GemmBatch b{};
             add(b, fwd(acts->h2m, H, 2, Z, mu, EPI_BIAS));
             add(b, fwd(acts->h2s, H, 5, Z, logvar, EPI_BIAS));
-            RET_IF(launch(b, 2));
+            LAUNCH(launch(b, 2));
         }
-        const void* al[] = {mu, logvar, eps_in, acts->eps, acts->z, acts->d1, P[12], P[13]};
-        static const bool bottleneck_on = getenv("PSVAE_NO_BOTTLENECK") == nullptr;
-        if (bottleneck_on && reparam_linear_ok(Z, H, al, 8)) {
+        if (bottleneck_on && bn_ok) {
             // reparameterisation + KL partials + decoder layer 0 (K = Z) as one dedicated launch
-            RET_IF(launch_reparam_linear(mu, logvar, eps_in, rng_state, seed, offset, P[12], P[13], acts->eps, acts->z,
-                                         acts->d1, sc.kl_partials, B, Z, H, s));
+            BnFwdArgs a{};
+            a.mu = mu; a.lv = logvar; a.S = fuse ? STAGE2_SLABS : 0;
+            a.slab_m = sc.slab_mu; a.slab_s = sc.slab_lv; a.b3m = P[5]; a.b3s = P[11];
+            a.eps_in = eps_in; a.rng = rng_state; a.seed = seed; a.offset = offset; a.W = P[12]; a.bias = P[13];
+            if (cond) { a.ctab = cond->tab[2]; a.gender = cond->gender; a.age = cond->age; }
+            a.eps_out = acts->eps; a.z_out = acts->z; a.Y = acts->d1; a.kl_partials = sc.kl_partials;
+            a.B = B; a.Z = Z; a.N = H;
+            LAUNCH(launch_bottleneck_fwd(a, s));
             n_kl = reparam_linear_tiles(B);
         } else {
-            RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
+            LAUNCH(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, acts->eps, acts->z, sc.kl_partials,
                                      (int64_t)B * Z, s));
             GemmBatch b{};
-            add(b, fwd(acts->z, Z, 6, H, acts->d1, EPI_BIAS_RELU));
-            RET_IF(launch(b, 3));
+            GemmDesc d1 = fwd(acts->z, Z, 6, H, acts->d1, EPI_BIAS_RELU);
+            set_cond(d1, cond, 2);
+            add(b, d1);
+            LAUNCH(launch(b, 3));
         }
         {
             GemmBatch b{};
             add(b, fwd(acts->d1, H, 7, H, acts->d2, EPI_BIAS_RELU));
-            RET_IF(launch(b, 4));
+            LAUNCH(launch(b, 4));
         }
         int n_recon = 0;
-        {  // decoder output + MSE gradient + MSE partial sums in one epilogue (lightning.py:113)
+        if (!variant) {  // decoder output + MSE gradient + MSE partial sums in one epilogue (lightning.py:113)
             GemmBatch b{};
             GemmDesc d = fwd(acts->d2, H, 8, D, x_hat, EPI_BIAS_RECON);
             d.aux2 = x;
@@ -490,23 +546,49 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             d.scale = 2.0f / (10.0f * (float)B * (float)D);
             d.partials = sc.recon_partials;
             add(b, d);
-            RET_IF(launch(b, 5));
+            LAUNCH(launch(b, 5));
             n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
             if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
+        } else {  // cosine loss and / or normalised decoder output: plain GEMM, then ONE row kernel
+            float* y = normalize ? sc.y : x_hat;
+            GemmBatch b{};
+            add(b, fwd(acts->d2, H, 8, D, y, EPI_BIAS));
+            LAUNCH(launch(b, 5));
+            LAUNCH(launch_recon_row(y, x, x_hat, acts->ynorm, sc.gy, sc.recon_partials, grad_loss, normalize, cos_loss, B, D, s));
+            n_recon = recon_row_blocks(B);
         }
         {
             GemmBatch b{};
             add(b, wgrad(6, 8, D, H, sc.gy, acts->d2));
             add(b, make_desc(GK_NN, B, H, D, sc.gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
-            RET_IF(launch(b, 6));
+            LAUNCH(launch(b, 6));
         }
         {
             GemmBatch b{};
             add(b, wgrad(7, 7, H, H, sc.dd2, acts->d1));
-            add(b, make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1));
-            RET_IF(launch(b, 7));
+            GemmDesc d = make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1);
+            if (fuse) { d.B2 = P[12]; d.slab2 = sc.slab_gz; d.Z2 = Z; }  // g_z partials: masked-tile(dd1) * Wd1 rows
+            add(b, d);
+            LAUNCH(launch(b, 7));
         }
-        {
+        if (fuse) {
+            BnBwdArgs a{};
+            a.slab_gz = sc.slab_gz; a.S = STAGE2_SLABS;
+            a.mu = mu; a.lv = logvar; a.eps = acts->eps; a.go = grad_loss; a.beta = beta;
+            a.g_mu = sc.gmu; a.g_lv = sc.glv; a.W3mT = WT[2]; a.W3sT = WT[5];
+            a.h2m = acts->h2m; a.h2s = acts->h2s; a.dh2m = sc.dh2m; a.dh2s = sc.dh2s;
+            a.kl_partials = sc.kl_partials; a.n_kl = n_kl; a.recon_partials = sc.recon_partials; a.n_recon = n_recon;
+            a.recon_mode = cos_loss ? 1 : 0; a.D = D; a.loss3 = loss3;
+            a.rng = eps_in ? nullptr : reinterpret_cast<unsigned long long*>(rng_state);
+            a.rng_adv = (unsigned long long)(((int64_t)B * Z + 3) / 4);
+            a.B = B; a.Z = Z; a.N = H;
+            LAUNCH(launch_bottleneck_bwd(a, s));
+            if (!all) {  // a decoder-only call must leave the decoder gradients complete
+                GemmBatch b{};
+                add(b, wgrad(8, 6, H, Z, sc.dd1, acts->z));
+                LAUNCH(launch(b, 8));
+            }
+        } else {
             GemmBatch b{};
             add(b, wgrad(8, 6, H, Z, sc.dd1, acts->z));
             // g_z = dd1 W never reaches memory: the epilogue turns it into g_mu / g_logvar (reparameterisation +
@@ -521,25 +603,28 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             d.n_kl = n_kl;
             d.partials = sc.recon_partials;
             d.n_recon = n_recon;
-            d.loss_D = D;
+            d.loss_D = cos_loss ? -D : D;  // negative: the partials are per-row cosine terms (recon = sum / B)
             d.loss3 = loss3;
             d.rng = eps_in ? nullptr : reinterpret_cast<unsigned long long*>(rng_state);
             d.rng_adv = (unsigned long long)(((int64_t)B * Z + 3) / 4);
             add(b, d);
-            RET_IF(launch(b, 8));
+            LAUNCH(launch(b, 8));
         }
-        if (!(phases & PSVAE_PHASE_ENCODER)) {  // a decoder-only call must leave the decoder gradients complete
-            RET_IF(wg.reduce(s));
+        if (cond) {
+            const float* dy[1] = {sc.dd1};
+            float* gt[1] = {cond->gtab[2]};
+            LAUNCH(launch_cond_colsum(dy, gt, 1, cond->gender, cond->age, B, H, s));
         }
+        if (!(phases & PSVAE_PHASE_ENCODER) && wg.n > 0) LAUNCH(wg.reduce(s));
     }
     if (phases & PSVAE_PHASE_ENCODER) {
-        {
+        if (!fuse) {
             GemmBatch b{};
             add(b, wgrad(9, 2, Z, H, sc.gmu, acts->h2m));
             add(b, wgrad(9, 5, Z, H, sc.glv, acts->h2s));
             add(b, make_desc(GK_NN, B, H, Z, sc.gmu, Z, P[4], H, sc.dh2m, H, EPI_MASK, acts->h2m));
             add(b, make_desc(GK_NN, B, H, Z, sc.glv, Z, P[10], H, sc.dh2s, H, EPI_MASK, acts->h2s));
-            RET_IF(launch(b, 9));
+            LAUNCH(launch(b, 9));
         }
         {
             GemmBatch b{};
@@ -547,16 +632,56 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
             add(b, wgrad(10, 4, H, H, sc.dh2s, acts->h1s));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
-            RET_IF(launch(b, 10));
+            LAUNCH(launch(b, 10));
         }
         {
             GemmBatch b{};
             add(b, wgrad(11, 0, H, D, sc.dh1m, x));
             add(b, wgrad(11, 3, H, D, sc.dh1s, x));
-            RET_IF(launch(b, 11));
+            if (fuse) {  // the Z-sized weight gradients ride along (their own launches sat on the launch floor)
+                add(b, wgrad(11, 2, Z, H, sc.gmu, acts->h2m));
+                add(b, wgrad(11, 5, Z, H, sc.glv, acts->h2s));
+                if (all) add(b, wgrad(11, 6, H, Z, sc.dd1, acts->z));
+            }
+            LAUNCH(launch(b, 11));
         }
-        RET_IF(wg.reduce(s));
+        if (cond) {
+            const float* dy[2] = {sc.dh1m, sc.dh1s};
+            float* gt[2] = {cond->gtab[0], cond->gtab[1]};
+            LAUNCH(launch_cond_colsum(dy, gt, 2, cond->gender, cond->age, B, H, s));
+        }
+        if (wg.n > 0) LAUNCH(wg.reduce(s));
     }
+#undef LAUNCH
+    return 0;
+}
+
+int psvae_last_step_launches(void) { return t_launches; }
+
+int psvae_transpose_params_f32(const psvae_dims* dims, const psvae_params* params, const psvae_params* params_kmajor,
+                               void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!params || !params_kmajor) return PSVAE_ERR_NULL;
+    const int64_t D = dims->D, Z = dims->Z;
+    const int64_t o[9] = {H, H, Z, H, H, Z, H, H, D}, in[9] = {D, H, H, D, H, H, Z, H, H};
+    const float* src[9]; float* dst[9]; int R[9], C[9];
+    for (int k = 0; k < 9; ++k) {
+        if (!params->p[2 * k] || !params_kmajor->p[2 * k]) return PSVAE_ERR_NULL;
+        src[k] = params->p[2 * k]; dst[k] = const_cast<float*>(params_kmajor->p[2 * k]); R[k] = (int)o[k]; C[k] = (int)in[k];
+    }
+    RET_IF(launch_transpose_f32(src, dst, R, C, 9, (hipStream_t)stream));
+    return 0;
+}
+
+int psvae_adam_step_dev_f32(const psvae_adam_dev* L, psvae_adam_state* state, double beta1, double beta2, double eps,
+                            double weight_decay, double grad_scale, void* stream) {
+    if (!L || !state || !L->param || !L->grad || !L->exp_avg || !L->exp_avg_sq) return PSVAE_ERR_NULL;
+    if (L->n_vec < 0 || L->n_vec > 16) return PSVAE_ERR_ARG;
+    for (int k = 0; k < 9; ++k)
+        if (L->mat_off[k] < 0 || L->mat_rows[k] <= 0 || L->mat_cols[k] <= 0) return PSVAE_ERR_SHAPE;
+    for (int k = 0; k < L->n_vec; ++k)
+        if (L->vec_off[k] < 0 || L->vec_len[k] < 0) return PSVAE_ERR_SHAPE;
+    RET_IF(launch_adam_dual(L, state, beta1, beta2, eps, weight_decay, grad_scale, (hipStream_t)stream));
     return 0;
 }
 
@@ -565,7 +690,8 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
 // for this (B, D, Z).  Every candidate computes the same result; only speed differs.
 int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psvae_params* params,
                               const psvae_acts* acts, float* x_hat, float* mu, float* logvar,
-                              const psvae_grads* grads, float* loss3, void* scratch, int iters, void* stream) {
+                              const psvae_grads* grads, float* loss3, void* scratch, int iters,
+                              const psvae_step_opts* opts, void* stream) {
     if (int e = check_dims(dims)) return e;
     if (iters < 1 || iters > 1000) return PSVAE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -577,14 +703,14 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     RET_IF(hipEventCreate(&e1));
     int rc = 0;
     auto measure = [&](const StepPlan& p, float* ms) -> int {
-        g_trial = &p;
+        t_trial = &p;
         int r = 0;
         for (int i = 0; i < 2 + iters && r == 0; ++i) {
             if (i == 2) hipEventRecord(e0, s);
             r = psvae_train_step_f32(dims, x, params, nullptr, 1234, (uint64_t)i * 4096, nullptr, acts, x_hat, mu, logvar,
-                                     1.0f, nullptr, grads, loss3, scratch, PSVAE_PHASE_ALL, stream);
+                                     1.0f, nullptr, grads, loss3, scratch, PSVAE_PHASE_ALL, opts, stream);
         }
-        g_trial = nullptr;
+        t_trial = nullptr;
         if (r) return r;
         hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess) return (int)hipGetLastError();
@@ -596,13 +722,20 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     float t_best = 0.f;
     rc = measure(best, &t_best);
     static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8, 7, 9};  // 7, 9: launches without wgrads only
+    // which launch sites exist in this configuration (mirrors psvae_train_step_f32)
+    const bool bn = getenv("PSVAE_NO_BOTTLENECK") == nullptr && (dims->Z & 15) == 0 && dims->Z <= 128;
+    const bool fuse = bn && getenv("PSVAE_NO_STAGE2") == nullptr && getenv("PSVAE_FWD_NT") == nullptr &&
+                      (dims->Z & 63) == 0;
     for (int pass = 0; pass < 2 && rc == 0; ++pass) {
         for (int site = 0; site < NSITE && rc == 0; ++site) {
-            // decoder layer 0 normally runs inside the bottleneck kernel: its GEMM site has nothing to tune
-            if (site == 3 && getenv("PSVAE_NO_BOTTLENECK") == nullptr && (dims->Z & 15) == 0 && dims->Z <= 128) continue;
+            // decoder layer 0 normally runs inside the bottleneck kernel: its GEMM site has nothing to tune; with the
+            // second-stage fusion the heads (F3), decoder.0's dgrad (B3) and the heads' dgrad (B4) have no launch either
+            if (site == 3 && bn) continue;
+            if (fuse && (site == 2 || site == 8 || site == 9)) continue;
             const bool has_tn = site >= 6, has_other = site != 11;
+            const bool s2 = fuse && (site == 1 || site == 7);  // second-stage launches: config 6 for the non-TN problems
             for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
-                for (int o = 0; o < (has_other ? (has_tn ? 5 : 7) : 1) && rc == 0; ++o)
+                for (int o = s2 ? 3 : 0; o < (s2 ? 4 : (has_other ? (has_tn ? 5 : 7) : 1)) && rc == 0; ++o)
                     for (int ks = 1; ks <= (has_tn ? WGRAD_SMAX : 1) && rc == 0; ks *= 2)
                         for (int capv = 1; capv <= 2 && rc == 0; ++capv)
                             for (int rm = 1; rm <= 2 && rc == 0; ++rm) {
@@ -639,7 +772,7 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
         float t_h = 0.f, t_b = 0.f;
         rc = confirm(heuristic, &t_h);
         if (rc == 0) rc = confirm(best, &t_b);
-        if (rc == 0 && t_b >= t_h) best = heuristic;
+        if (rc == 0 && t_b >= 0.99f * t_h) best = heuristic;  // a tuned plan must win by a margin, else heuristics
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);

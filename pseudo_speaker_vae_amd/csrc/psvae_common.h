@@ -47,7 +47,8 @@ struct GemmDesc {
     float* loss3;           // {total, recon, kl}
     unsigned long long* rng;     // nullable: rng[1] += rng_adv
     unsigned long long rng_adv;
-    int n_kl, n_recon, loss_D;  // `partials` holds the n_recon squared-error partial sums; loss_D = input dim
+    int n_kl, n_recon, loss_D;  // `partials` holds the n_recon loss partial sums; loss_D = input dim (MSE: sum/(M D)/10),
+                                // or -D when they are per-row cosine terms (recon = sum / M)
     int M, N, K;
     int lda, ldb, ldc;
     int kind, epi;
@@ -56,6 +57,14 @@ struct GemmDesc {
                  // C + s*M*ldc and its partial column sums to colsum + s*M (summed later by launch_slab_reduce)
     int tiles_m, tiles_n;
     int tile_begin;  // first linear tile of this problem inside the launch
+    // Second stage (config 6 only; nullable): after the epilogue the finished 64 x 64 tile T (post bias/ReLU or post mask)
+    // is multiplied from LDS with rows [n0, n0+64) of B2[N, Z2] (row-major, Z2 % 64 == 0):
+    //   slab2[tn][row][0..Z2) = T[row][:] * B2[n0.., :]        (one partial product per column tile tn of this problem)
+    // The consumer sums the tiles_n partials in fixed order.  Folds the skinny layer that FOLLOWS this one (mu / logvar
+    // heads after encoder layer 1, decoder.0's dgrad after decoder.2's) into this launch: N % 64 == 0 required.
+    const float* B2;
+    float* slab2;
+    int Z2;
 };
 
 constexpr int MAX_GROUP = 6;
@@ -99,6 +108,7 @@ inline GemmDesc make_desc(int kind, int M, int N, int K, const float* A, int lda
     d.ksplit = 1;
     d.aux3 = nullptr; d.kl_part = nullptr; d.loss3 = nullptr; d.rng = nullptr; d.rng_adv = 0;
     d.n_kl = 0; d.n_recon = 0; d.loss_D = 0;
+    d.B2 = nullptr; d.slab2 = nullptr; d.Z2 = 0;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.kind = kind; d.epi = epi;
     return d;
 }
@@ -153,12 +163,70 @@ hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in,
 // leaves the rng advance to launch_reparam_bwd_final
 int reparam_blocks(int64_t n);
 // reparameterisation + KL partials + decoder layer 0 in one launch (Z % 16 == 0, Z <= 128, N % 4 == 0, 16-B aligned
-// pointers); kl_partials gets reparam_linear_tiles(B) entries
+// pointers); kl_partials gets reparam_linear_tiles(B) entries (bottleneck.hip)
 bool reparam_linear_ok(int Z, int N, const void* const* ptrs, int nptr);
 int reparam_linear_tiles(int B);
 hipError_t launch_reparam_linear(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
                                  uint64_t seed, uint64_t offset, const float* W, const float* bias, float* eps_out,
                                  float* z_out, float* Y, float* kl_partials, int B, int Z, int N, hipStream_t s);
+struct BnFwdArgs {
+    // S == 0: mu / lv hold the finished heads' outputs (read).  S >= 1: mu = b3m + sum_s slab_m[s], lv likewise, and
+    // the column-0 workgroups write them to mu / lv.
+    float* mu;
+    float* lv;
+    const float* slab_m;  // [S][B][Z]
+    const float* slab_s;
+    const float* b3m;     // [Z]
+    const float* b3s;
+    int S;
+    const float* eps_in;          // nullable: injected epsilon
+    const uint64_t* rng;          // nullable: device {seed, offset}
+    uint64_t seed, offset;
+    const float* W;               // decoder.0 weight [N, Z] (k contiguous)
+    const float* bias;            // [N]
+    const float* ctab;            // nullable: conditional table [6, N]
+    const int32_t* gender;
+    const int32_t* age;
+    float* eps_out;               // [B, Z]
+    float* z_out;                 // [B, Z]
+    float* Y;                     // [B, N] = relu(z W^T + bias (+ table rows))
+    float* kl_partials;           // one per 16-row tile
+    int B, Z, N;
+};
+
+struct BnBwdArgs {
+    const float* slab_gz;   // [S][B][Z]
+    int S;
+    const float* mu;
+    const float* lv;
+    const float* eps;
+    const float* go;        // nullable device scalar (upstream d loss)
+    float beta;
+    float* g_mu;            // [B, Z] out (the heads' weight gradients read them later)
+    float* g_lv;
+    const float* W3mT;      // k-major copies [N, Z] of encoder_mu.4 / encoder_sigma.4 weights ([Z, N] row-major originals)
+    const float* W3sT;
+    const float* h2m;       // [B, N] saved post-ReLU activations = masks
+    const float* h2s;
+    float* dh2m;            // [B, N] out
+    float* dh2s;
+    // loss finalisation
+    const float* kl_partials; int n_kl;
+    const float* recon_partials; int n_recon;
+    int recon_mode;         // 0: recon = sum / (B D) / 10 (MSE, lightning.py:113); 1: recon = sum / B (cosine, :111)
+    int D;
+    float* loss3;
+    unsigned long long* rng; unsigned long long rng_adv;
+    int B, Z, N;
+};
+
+hipError_t launch_bottleneck_fwd(const BnFwdArgs& a, hipStream_t s);
+hipError_t launch_bottleneck_bwd(const BnBwdArgs& a, hipStream_t s);
+int recon_row_blocks(int B);
+hipError_t launch_recon_row(const float* y, const float* x, float* xh, float* ynorm, float* g_y, float* partials,
+                            const float* go, bool normalize, bool cos_loss, int B, int D, hipStream_t s);
+hipError_t launch_adam_dual(const psvae_adam_dev* L, psvae_adam_state* st, double b1, double b2, double eps, double wd,
+                            double gscale, hipStream_t s);
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
                              uint64_t seed, uint64_t offset, float* eps_out, float* z, float* kl_partials,
                              int64_t n, hipStream_t s, unsigned short* zb = nullptr, unsigned short* zbT = nullptr,

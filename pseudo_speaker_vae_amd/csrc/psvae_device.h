@@ -1,0 +1,56 @@
+// Device-side helpers shared by the elementwise / row kernels (gfx950): Philox4x32-10 + Box-Muller, wave and block sums.
+#pragma once
+#include "psvae_common.h"
+
+namespace psvae {
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  One lane = one Philox block = 4 normals for 4 consecutive
+// elements, so a wavefront covers 256 contiguous elements and stores 16 B per lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t blk, uint64_t seed) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    constexpr float S = 5.9604644775390625e-08f;  // 2^-24
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * S, u1 = ((float)(r[1] >> 8) + 0.5f) * S;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * S, u3 = ((float)(r[3] >> 8) + 0.5f) * S;
+    constexpr float TWO_PI = 6.283185307179586f;
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincosf(TWO_PI * u1, &sa, &ca);
+    sincosf(TWO_PI * u3, &sb, &cb);
+    return f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// fixed-order sum over the 256 threads of a block; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* sh4) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+}  // namespace psvae

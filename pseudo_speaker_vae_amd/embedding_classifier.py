@@ -28,6 +28,8 @@ def consistency_ce_raw(x_hat, y, params, grad_scale: float = 1.0, want_param_gra
     B, D = x_hat.shape
     ps = [p.detach().float().contiguous() for p in params]
     hidden, C = ps[0].shape[0], ps[4].shape[0]
+    from .latent_classifier import check_labels
+    check_labels(y, C, "EmbeddingClassifier (consistency) cross entropy")
     lib = _ffi.lib()
     scratch = torch.empty(int(lib.psvae_consistency_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=x_hat.device)
     loss2 = torch.empty(2, dtype=torch.float32, device=x_hat.device)

@@ -3,15 +3,21 @@
 One process per GPU.  Parameters, gradients and Adam state live in flat fp32 buffers (the 18 tensors
 in the reference's creation order, model.py:14-36, each 256-B aligned), so that
   * the HIP kernels write gradients straight into the all-reduce payload,
-  * data-parallel averaging (the reference's DDPStrategy, training.py:78) is TWO RCCL all-reduces
-    per step: the decoder bucket is issued as soon as backward phase 1 has been enqueued and runs
-    on RCCL's stream underneath the encoder backward (phase 2); the encoder bucket carries the three
-    loss scalars too (replaces Lightning's per-key `sync_dist` all-reduces, lightning.py:127-129),
-  * Adam (lightning.py:205) is one fused kernel over the flat buffer with the 1/world scale folded in.
-On one GPU the whole step (forward + ELBO + backward [+ Adam]) can be captured into a HIP graph.
+  * data-parallel averaging (the reference's DDPStrategy, training.py:78) is ONE RCCL all-reduce of the flat buffer
+    after the captured step (or two bucketed ones, decoder first, overlapped with the encoder backward in the eager
+    mode); the three loss scalars ride in the payload (replaces Lightning's per-key `sync_dist` all-reduces,
+    lightning.py:127-129),
+  * Adam (lightning.py:205) is one fused kernel over the flat buffers; its step counter and learning rate live on the
+    device, so the optimizer can be captured in the step's HIP graph and CosineAnnealingLR (lightning.py:206-213) is
+    one small device write per epoch (`scheduler_step`),
+  * the optimizer also maintains the k-major ([in, out]) copies of the weight matrices the forward GEMMs read
+    (`flat_params_t`): the training pass itself then needs no per-step weight transpose.
+On one GPU the whole step (forward + ELBO + backward [+ Adam]) is captured into a HIP graph.
 """
 from __future__ import annotations
 
+import math
+import struct
 from typing import List, Optional
 
 import torch
@@ -52,8 +58,34 @@ class FlatLayout:
     def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
         return [flat[o:o + s.numel()].view(s) for o, s in zip(self.offsets, self.shapes)]
 
+    def kmajor_views(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        """the same offsets read as the k-major copies: weight k is [in, out]; bias slots alias the (unused) range"""
+        out = []
+        for o, s in zip(self.offsets, self.shapes):
+            v = flat[o:o + s.numel()]
+            out.append(v.view(s[1], s[0]) if len(s) == 2 else v.view(s))
+        return out
+
     def extra_views(self, flat: torch.Tensor) -> List[torch.Tensor]:
         return [flat[o:o + s.numel()].view(s) for o, s in zip(self.extra_offsets, self.extra_shapes)]
+
+    def adam_layout(self, param, param_kmajor, grad, exp_avg, exp_avg_sq) -> "_ffi.AdamDev":
+        L = _ffi.AdamDev()
+        L.param, L.grad, L.exp_avg, L.exp_avg_sq = (_ffi.ptr(t) for t in (param, grad, exp_avg, exp_avg_sq))
+        L.param_kmajor = _ffi.ptr(param_kmajor) if param_kmajor is not None else None
+        nv = 0
+        for i, (o, s) in enumerate(zip(self.offsets, self.shapes)):
+            if len(s) == 2:
+                k = i // 2
+                L.mat_off[k], L.mat_rows[k], L.mat_cols[k] = o, s[0], s[1]
+            else:
+                L.vec_off[nv], L.vec_len[nv] = o, s.numel()
+                nv += 1
+        for o, s in zip(self.extra_offsets, self.extra_shapes):
+            L.vec_off[nv], L.vec_len[nv] = o, s.numel()
+            nv += 1
+        L.n_vec = nv
+        return L
 
 
 class TrainEngine:
@@ -61,20 +93,20 @@ class TrainEngine:
                  beta: float = 1.0, normalize_decoder: bool = False, use_cos_loss: bool = False,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  process_group=None, state_dict=None, dtype: str = "f32", conditional: bool = False,
-                 shard: Optional[tuple] = None):
+                 shard: Optional[tuple] = None, scheduler: Optional[dict] = None):
         """dtype "bf16" = BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulate / master weights /
-        gradients); conditional = one-hot gender+age gather tables."""
+        gradients); conditional = one-hot gender+age gather tables (SURVEY.md section 8a row A9), either dtype;
+        scheduler = CosineAnnealingLR keyword arguments {"T_max": .., "eta_min": ..} (lightning.py:206)."""
         if dtype not in ("f32", "bf16"):
             raise ValueError(dtype)
-        if conditional and dtype != "bf16":
-            raise ValueError("the conditional engine path is wired for dtype='bf16' (config 3); "
-                             "fp32 conditioning is available through ConditionalVAEModel")
         self.dtype, self.conditional = dtype, conditional
         self.D, self.Z, self.B = input_dim, latent_dim, batch
         self.device = torch.device(device)
         self.beta = float(beta)
         self.flags = (_ffi.NORMALIZE_DECODER if normalize_decoder else 0) | (_ffi.COS_LOSS if use_cos_loss else 0)
-        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.base_lr, self.betas, self.adam_eps, self.weight_decay = float(lr), betas, eps, weight_decay
+        self.scheduler = dict(scheduler) if scheduler else None
+        self.epoch = 0
         self.pg = process_group
         self.world = 1
         self.rank = 0
@@ -98,10 +130,8 @@ class TrainEngine:
         extra = [torch.Size((_ffi.COND_DIM, _ffi.HIDDEN))] * 3 if conditional else None
         self.layout = FlatLayout([p.shape for p in src], extra)
         n = self.layout.total
-        self.flat_params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
         self.params = self.layout.views(self.flat_params)
         self.grads = self.layout.views(self.flat_grads)
         for dst, s in zip(self.params, src):
@@ -110,14 +140,15 @@ class TrainEngine:
         # bucket 0 = encoders + loss scalars, bucket 1 = decoder (reduced first: its grads are ready first)
         self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group) \
             if process_group is not None else None
-        if process_group is not None:
-            broadcast_flat(self.flat_params, 0, process_group)
         self.cond_tabs = self.layout.extra_views(self.flat_params)
         self.cond_gtabs = self.layout.extra_views(self.flat_grads)
         for t in self.cond_tabs:  # nn.Linear-like init of the extra one-hot columns (same seed on every rank)
             bound = 1.0 / (input_dim + _ffi.COND_DIM) ** 0.5
             t.copy_(torch.empty(t.shape).uniform_(-bound, bound))
+        if process_group is not None:
+            broadcast_flat(self.flat_params, 0, process_group)
         self.gender = self.age = self._cond = None
+        self.flat_params_t = self.params_t = None
         if dtype == "bf16":
             if self.flags != 0:
                 raise ValueError("the bf16 path implements the default loss (MSE/10 + beta*KL)")
@@ -126,6 +157,15 @@ class TrainEngine:
         else:
             self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
             self.outs = self.ws.new_outputs()
+            # k-major copies of the weight matrices, same flat layout; made once here, then kept current by Adam
+            self.flat_params_t = z()
+            self.params_t = self.layout.kmajor_views(self.flat_params_t)
+            self.refresh_kmajor()
+        # Adam: {lr, step} live on the device (graph-safe); one fused launch over the flat buffers
+        self.adam_state = torch.zeros(24, dtype=torch.uint8, device=self.device)
+        self._write_lr(self.base_lr)
+        self._adam_layout = self.layout.adam_layout(self.flat_params, self.flat_params_t, self.flat_grads,
+                                                    self.exp_avg, self.exp_avg_sq)
         self.step_count = 0
         # device-resident Philox state {seed, offset}: advanced by the forward itself (graph-safe).  Data-parallel
         # ranks share the seed and interleave their counter ranges by GLOBAL row index: rank r starts
@@ -135,11 +175,30 @@ class TrainEngine:
         self.rng_state = torch.tensor([seed, self.rank * self._nblk], dtype=torch.int64, device=self.device)
         self._rng_skip = (self._eps_world - 1) * self._nblk
         self._graph = None
+        self._adam_in_graph = False
+        self._collective_in_graph = False
         self.static_x = None
 
     # ------------------------------------------------------------------------------------------
     def state_dict(self):
         return {k: p.detach().clone() for k, p in zip(self.keys, self.params)}
+
+    def refresh_kmajor(self):
+        """re-make the k-major weight copies from flat_params (after loading / overwriting parameters by hand; the
+        engine's own optimizer keeps them current)"""
+        if self.params_t is not None:
+            ops.transpose_params(self.ws, self.params, self.params_t)
+
+    def _step_kwargs(self):
+        return dict(params_kmajor=self.params_t, cond=self._cond, flags=self.flags)
+
+    def launches_per_step(self) -> Optional[int]:
+        """kernel launches of one forward+ELBO+backward pass as this engine issues it (measured: the library counts
+        the launches of the calling thread's last psvae_train_step_f32).  None for the bf16 path (not instrumented)."""
+        if self.dtype != "f32":
+            return None
+        n = ops.last_step_launches()
+        return n if n > 0 else None
 
     def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):
         self._forward_backward(x, eps, _local_only)
@@ -154,6 +213,8 @@ class TrainEngine:
     def _forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):
         """forward + ELBO + backward (+ overlapped gradient all-reduce when data-parallel).
         Leaves averaged gradients in self.grads and {total, recon, kl} in self.loss3."""
+        if self.conditional and self._cond is None:
+            raise _ffi.PsvaeError("conditional engine: call set_labels(gender, age) for this batch first")
         if self.dtype == "bf16":
             ops.train_step_bf16(self.ws, x, self.params, self.grads, self.loss3, beta=self.beta, eps=eps,
                                 rng_state=self.rng_state, cond=self._cond)
@@ -161,97 +222,123 @@ class TrainEngine:
                 self.averager.reduce_all()
                 self.averager.wait()
             return
-        if self.flags == 0:  # default loss: the fused 13-launch sequence
-            kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state)
-            if self.averager is None or _local_only:
-                ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
-                return
-            ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
-            self.averager.reduce_bucket(1)             # decoder grads: runs under the encoder backward
-            ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_ENCODER, **kw)
-            self.averager.reduce_bucket(0)             # encoder grads + the 3 loss scalars
-            self.averager.wait()
-            return
-        xh, mu, lv = ops.vae_forward(self.ws, x, self.params, eps, 0, 0, self.flags, outs=self.outs,
-                                     rng_state=self.rng_state)
-        ops.elbo(self.ws, x, xh, mu, lv, self.beta, self.flags, self.loss3)
+        kw = dict(beta=self.beta, eps=eps, rng_state=self.rng_state, **self._step_kwargs())
         if self.averager is None or _local_only:
-            ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
-                             flags=self.flags)
+            ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, **kw)
             return
-        ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
-                         flags=self.flags, phases=_ffi.PHASE_DECODER)
-        self.averager.reduce_bucket(1)                 # decoder grads: runs under the encoder backward
-        ops.vae_backward(self.ws, x, self.params, xh, mu, lv, self.grads, elbo_grad=True, beta=self.beta,
-                         flags=self.flags, phases=_ffi.PHASE_ENCODER)
-        self.averager.reduce_bucket(0)                 # encoder grads + the 3 loss scalars
+        ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
+        self.averager.reduce_bucket(1)             # decoder grads: runs under the encoder backward
+        ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_ENCODER, **kw)
+        self.averager.reduce_bucket(0)             # encoder grads + the 3 loss scalars
         self.averager.wait()
 
-    def tune(self, x: torch.Tensor, iters: int = 10, plan: Optional[str] = None) -> str:
-        """Autotune the fused step's launch plan for this batch shape (fp32, default loss, unconditional only;
-        a no-op otherwise).  Takes a few seconds once (or no time with a plan cache file, $PSVAE_PLAN_CACHE); later
-        steps -- eager or captured -- use the plan.  Gradients,
-        outputs and the loss buffer are overwritten.  Returns the plan's text form."""
-        if self.dtype != "f32" or self.flags != 0 or self.conditional:
+    def tune(self, x: torch.Tensor, iters: int = 10, plan: Optional[str] = None, force: bool = False) -> str:
+        """Install the fused step's launch plan for this batch shape (fp32 only; a no-op otherwise) and return its text
+        form.  Order: an explicit `plan`; else the entry for this GPU model and (B, D, Z) in the committed plan file
+        (pseudo_speaker_vae_amd/launch_plans.json, or $PSVAE_PLAN_CACHE) -- so two runs on two boxes use the SAME
+        plan; else (or with force=True) measure: psvae_tune_train_step_f32 times the whole step per candidate for a few
+        seconds and keeps a candidate only if it beats the heuristic plan by a margin in the same session.
+        Gradients, outputs and the loss buffer are overwritten by a measurement."""
+        if self.dtype != "f32":
             return "untuned"
         if plan is not None:  # reuse a plan tuned earlier (text form) instead of measuring
             ops.set_plan(self.ws, plan)
             return ops.describe_plan(self.ws)
-        return ops.tune_or_load_plan(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters)
+        if self.flags != 0 or self.conditional:
+            # the tuner drives the default-loss unconditional step; the variants share that shape's plan
+            return ops.load_committed_plan(self.ws) or "untuned"
+        return ops.tune_or_load_plan(self.ws, x, self.params, self.grads, self.outs, self.loss3, iters=iters,
+                                     force=force, params_kmajor=self.params_t)
 
     def set_labels(self, gender: torch.Tensor, age: torch.Tensor):
         """conditional engines: integer labels in {-1,0,1,2} for the current batch (labels.py maps)"""
         assert self.conditional
-        self.gender = gender.to(device=self.device, dtype=torch.int32).contiguous()
-        self.age = age.to(device=self.device, dtype=torch.int32).contiguous()
-        self._cond = _ffi.make_cond(self.cond_tabs, self.cond_gtabs, self.gender, self.age)
-
-    def optimizer_step(self, lr: Optional[float] = None):
-        """fused Adam over the flat buffers (lightning.py:205)."""
-        self.step_count += 1
-        ops.adam_step(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.step_count,
-                      self.lr if lr is None else lr, self.betas, self.adam_eps, self.weight_decay)
-        # the loss slot inside flat_grads is "trained" too but belongs to no parameter: harmless
+        if self.gender is None:
+            self.gender = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            self.age = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            self._cond = _ffi.make_cond(self.cond_tabs, self.cond_gtabs, self.gender, self.age)
+        self.gender.copy_(gender.to(torch.int32))  # static buffers: a captured step sees the new labels
+        self.age.copy_(age.to(torch.int32))
 
     # ------------------------------------------------------------------------------------------
-    def capture(self, x: torch.Tensor):
-        """Capture forward + ELBO + backward into one HIP graph (single GPU; launch-bound otherwise:
-        13-19 kernels of a few microseconds each).  The captured step reads its batch from a static
-        buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which
-        the graph itself advances, so every replay draws fresh noise."""
-        self.static_x = x.detach().clone()
+    def _write_lr(self, lr: float):
+        """one 8-byte host-to-device write into the Adam state (the captured optimizer reads lr from there)"""
+        self.lr = float(lr)
+        b = torch.frombuffer(bytearray(struct.pack("<d", self.lr)), dtype=torch.uint8)
+        self.adam_state[:8].copy_(b)
+
+    def scheduler_step(self, epoch: Optional[int] = None) -> float:
+        """CosineAnnealingLR stepped once per epoch (lightning.py:206-213, 'interval': 'epoch'): closed form
+        eta_min + (base_lr - eta_min) (1 + cos(pi t / T_max)) / 2.  Without a scheduler the rate stays base_lr."""
+        self.epoch = self.epoch + 1 if epoch is None else int(epoch)
+        if self.scheduler:
+            T, eta_min = self.scheduler["T_max"], self.scheduler.get("eta_min", 0.0)
+            self._write_lr(eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * self.epoch / T)) / 2)
+        return self.lr
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """fused Adam over the flat buffers (lightning.py:205), k-major weight copies included; the 1/world gradient
+        scale is already applied by the averaging all-reduce."""
+        if lr is not None and lr != self.lr:
+            self._write_lr(lr)
+        self.step_count += 1
+        ops.adam_step_dev(self._adam_layout, self.adam_state, self.betas, self.adam_eps, self.weight_decay)
+
+    def adam_steps_done(self) -> int:
+        """the device-side step counter (a host sync)"""
+        return struct.unpack("<q", self.adam_state[8:16].cpu().numpy().tobytes())[0]
+
+    # ------------------------------------------------------------------------------------------
+    def _warm(self, body, n=2):
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(2):  # warm-up outside capture (hipFuncSetAttribute, lazy module load)
-                self.forward_backward(self.static_x, _local_only=True)
+            for _ in range(n):  # warm-up outside capture (hipFuncSetAttribute, lazy module load, communicator setup)
+                body()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+
+    def capture(self, x: torch.Tensor, with_adam: bool = False):
+        """Capture forward + ELBO + backward (and, with_adam, the optimizer step: single GPU only -- with a process
+        group the all-reduce sits between them) into one HIP graph.  The captured step reads its batch from a static
+        buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which the graph itself
+        advances, so every replay draws fresh noise; Adam's step counter is device-resident too."""
+        if with_adam and self.averager is not None:
+            raise _ffi.PsvaeError("capture(with_adam=True) is the single-GPU form: the all-reduce comes between")
+        self.static_x = x.detach().clone()
+
+        def body():
+            self.forward_backward(self.static_x, _local_only=True)
+            if with_adam:
+                ops.adam_step_dev(self._adam_layout, self.adam_state, self.betas, self.adam_eps, self.weight_decay)
+        self._warm(body)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.forward_backward(self.static_x, _local_only=True)
+            body()
         self._graph = g
+        self._adam_in_graph = with_adam
+        self._collective_in_graph = False
         return g
 
     def replay(self):
         """one captured step; with a process group: followed by ONE all-reduce of the flat gradient buffer
         (the collective itself stays outside the graph)"""
         self._graph.replay()
-        if self.averager is not None and not getattr(self, "_collective_in_graph", False):
+        if self.averager is not None and not self._collective_in_graph:
             self.averager.reduce_all()
             self.averager.wait()
 
     def capture_with_collective(self, x: torch.Tensor, overlap: bool = True):
         """Data-parallel step as ONE HIP graph, RCCL all-reduce(s) included (RCCL kernels are capturable): no
         host-side stream hand-offs per step.  overlap=True: the decoder bucket's all-reduce is a parallel branch
-        of the graph under the encoder backward (default loss only); else one all-reduce at the end.
+        of the graph under the encoder backward; else one all-reduce at the end.
         Raises if the collective cannot be captured -- callers fall back to capture() + replay()."""
         import torch.distributed as dist
         if self.averager is None or self.averager.backend != "nccl":
             raise _ffi.PsvaeError("capture_with_collective needs an RCCL (nccl) process group")
         self.static_x = x.detach().clone()
-        split = overlap and self.dtype == "f32" and self.flags == 0
-        kw = dict(beta=self.beta, rng_state=self.rng_state)
+        split = overlap and self.dtype == "f32"
+        kw = dict(beta=self.beta, rng_state=self.rng_state, **(self._step_kwargs() if self.dtype == "f32" else {}))
 
         def body():
             if split:
@@ -267,38 +354,29 @@ class TrainEngine:
                 self.averager.reduce_all()
             self.averager.wait()
 
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(3):  # warm-up outside capture: communicator setup, lazy module load
-                body()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
+        self._warm(body, 3)
         dist.barrier(group=self.averager.pg)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             body()
         self._graph = g
         self._collective_in_graph = True
+        self._adam_in_graph = False
         return g
 
     def capture_ddp(self, x: torch.Tensor):
-        """Data-parallel variant: the step cannot be ONE graph (the RCCL all-reduces stay eager), so capture
-        its two halves -- [forward + ELBO + decoder backward] and [encoder backward] -- and replay them around
-        the collectives: graph A, all-reduce(decoder bucket) on RCCL's stream, graph B underneath it,
-        all-reduce(encoder bucket + loss scalars), wait.  Host cost per step: two graph launches + two
-        collective calls instead of 13 kernel launches."""
-        if self.averager is None or self.flags != 0:
-            raise _ffi.PsvaeError("capture_ddp needs a process group and the default loss")
+        """Data-parallel variant with the collectives eager: capture the step's two halves -- [forward + ELBO + decoder
+        backward] and [encoder backward] -- and replay them around the collectives: graph A, all-reduce(decoder
+        bucket) on RCCL's stream, graph B underneath it, all-reduce(encoder bucket + loss scalars), wait."""
+        if self.averager is None or self.dtype != "f32":
+            raise _ffi.PsvaeError("capture_ddp needs a process group and the fp32 path")
         self.static_x = x.detach().clone()
-        kw = dict(beta=self.beta, rng_state=self.rng_state)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3, **kw)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
+        kw = dict(beta=self.beta, rng_state=self.rng_state, **self._step_kwargs())
+
+        def warm():
+            ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3, **kw)
+            self._skip_rng()
+        self._warm(warm)
         self._ga, self._gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._ga):
             ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,

@@ -15,6 +15,18 @@ import torch.nn as nn
 from . import _ffi
 
 
+def check_labels(y: torch.Tensor, C: int, what: str = "classifier") -> None:
+    """The reference's F.cross_entropy raises on a label outside [0, C) (lightning.py:79 is fed the raw label maps, whose
+    "unknown" is -1: utils.py:103,120,136).  Same here, by default: one small device reduction + host read per step.
+    PSVAE_CHECK_LABELS=0 skips it; the fused kernels then poison the loss with NaN for such rows instead."""
+    import os
+    if os.environ.get("PSVAE_CHECK_LABELS", "1") == "0":
+        return
+    if bool(((y < 0) | (y >= C)).any()):
+        bad = y[(y < 0) | (y >= C)][:4].tolist()
+        raise _ffi.PsvaeError(f"{what}: label out of range [0, {C}): {bad} (map unknown labels out of the batch first)")
+
+
 def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
     """psvae_classifier_ce_f32 on detached tensors: returns loss2 = {mean CE, hits}, g_z and the parameter gradients
     (all times grad_scale)"""
@@ -25,6 +37,7 @@ def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
     W1, b1 = ps[0], ps[1]
     W2, b2 = (ps[2], ps[3]) if hidden else (None, None)
     C = (W2 if hidden else W1).shape[0]
+    check_labels(y, C, "LatentClassifier cross entropy")
     lib = _ffi.lib()
     scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=z.device)
     loss2 = torch.empty(2, dtype=torch.float32, device=z.device)

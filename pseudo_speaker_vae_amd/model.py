@@ -8,6 +8,7 @@ torch.autograd.Functions; inputs must live on the GPU -- there is no CPU fallbac
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -25,6 +26,7 @@ class _Buffers:
 
     def __init__(self):
         self._scratch: Dict[tuple, torch.Tensor] = {}
+        self.last_ctx = lambda: None  # weak reference to the most recent call's context (tests read its activations)
 
     def scratch(self, B, D, Z, device) -> torch.Tensor:
         key = (B, D, Z, str(device))
@@ -84,7 +86,7 @@ _FUSED_AUTOGRAD = os.environ.get("PSVAE_AUTOGRAD_FUSED", "1") != "0"  # tuning s
 
 class _Ctx:
     """what backward needs, shared by both Functions"""
-    __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors")
+    __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors", "__weakref__")
 
 
 def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_tensors=None):
@@ -107,12 +109,14 @@ def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_te
     c.cond_tensors = cond_tensors
     ws = _WsView(c)
     cond = _make_cond(cond_tensors, None)
+    buffers.last_ctx = weakref.ref(c)
     ops.vae_forward(ws, x, params, eps, seed, offset, flags, cond=cond, outs=(xh, mu, lv))
     return c, x, xh, mu, lv
 
 
-def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers):
-    """psvae_train_step_f32 on fresh buffers: returns ctx, outputs, the loss triple and the 18 gradients (d total = 1)"""
+def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers, flags: int = 0, cond_tensors=None):
+    """psvae_train_step_f32 on fresh buffers: returns ctx, outputs, the loss triple and the gradients (d total = 1):
+    the 18 parameter gradients, then the three conditional-table gradients when cond_tensors is given"""
     if not x.is_cuda:
         raise _ffi.PsvaeError("VAEModel runs on the GPU only (HIP kernels); move the module and its input to cuda")
     x = x.contiguous()
@@ -123,16 +127,20 @@ def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers):
     if params[0].shape[1] != D:
         raise _ffi.PsvaeError(f"input has {D} features, the model expects {params[0].shape[1]}")
     c = _Ctx()
-    c.B, c.D, c.Z, c.flags = B, D, Z, 0
-    c.acts, xh, mu, lv = _alloc_acts(B, D, Z, x.device, False)
+    c.B, c.D, c.Z, c.flags = B, D, Z, flags
+    c.acts, xh, mu, lv = _alloc_acts(B, D, Z, x.device, bool(flags & _ffi.NORMALIZE_DECODER))
     c.acts_c = _ffi.make_acts(c.acts)
     c.scratch = buffers.scratch(B, D, Z, x.device)
     c.dims = _ffi.Dims(B, D, Z)
-    c.cond_tensors = None
+    c.cond_tensors = cond_tensors
     grads = _alloc_grads(params)
+    gtabs = _alloc_grads(cond_tensors[0]) if cond_tensors is not None else []
+    cond = _make_cond(cond_tensors, gtabs) if cond_tensors is not None else None
     loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
-    ops.train_step(_WsView(c), x, params, grads, (xh, mu, lv), loss3, beta=beta, eps=eps, seed=seed, offset=offset)
-    return c, x, xh, mu, lv, loss3, grads
+    buffers.last_ctx = weakref.ref(c)
+    ops.train_step(_WsView(c), x, params, grads, (xh, mu, lv), loss3, beta=beta, eps=eps, seed=seed, offset=offset,
+                   cond=cond, flags=flags)
+    return c, x, xh, mu, lv, loss3, grads + gtabs
 
 
 def _make_cond(cond_tensors, gtabs):
@@ -191,10 +199,11 @@ class ELBOStepFunction(torch.autograd.Function):
         if ncond:
             cond_tensors = (params[_ffi.NPARAM:], cond_tensors[1], cond_tensors[2])
         ctx.fused_grads = None
-        if flags == 0 and not ncond and any(ctx.needs_input_grad[3:]) and _FUSED_AUTOGRAD:
-            # default loss, parameters want gradients: run the fused 13-launch train step now (forward + ELBO +
-            # backward with d(total) = 1) and hand the gradients out, scaled, when backward() is called
-            c, x, xh, mu, lv, loss3, grads = _run_fused_step(x.detach(), eps, seed, offset, beta, vae_params, buffers)
+        if any(ctx.needs_input_grad[3:]) and _FUSED_AUTOGRAD:
+            # parameters want gradients: run the fused train step now (forward + ELBO + backward with d(total) = 1; every
+            # loss variant, with or without the conditional tables) and hand the gradients out, scaled, in backward()
+            c, x, xh, mu, lv, loss3, grads = _run_fused_step(x.detach(), eps, seed, offset, beta, vae_params, buffers,
+                                                             flags, cond_tensors if ncond else None)
             ctx.fused_grads = grads
         else:
             c, x, xh, mu, lv = _run_forward(x.detach(), eps, seed, offset, flags, vae_params, buffers, cond_tensors)

@@ -121,52 +121,104 @@ def vae_backward(ws: Workspace, x, params: Sequence[torch.Tensor], xh, mu, lv, g
 def train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], outs, loss3,
                beta: float = 1.0, eps: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
                rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
-               phases: int = _ffi.PHASE_ALL):
-    """fused forward + ELBO + backward (default loss): psvae_train_step_f32"""
+               phases: int = _ffi.PHASE_ALL, params_kmajor: Optional[Sequence[torch.Tensor]] = None, cond=None,
+               flags: int = 0):
+    """fused forward + ELBO + backward: psvae_train_step_f32.  params_kmajor: the k-major ([in, out]) copies of the
+    18-slot parameter list (weights transposed, bias slots ignored) when the caller maintains them (TrainEngine does);
+    cond: a _ffi.Cond (one-hot tables); flags: NORMALIZE_DECODER | COS_LOSS."""
     P = _ffi.make_params(params)
     G = _ffi.make_grads(grads)
+    PK = _ffi.make_params(params_kmajor) if params_kmajor is not None else None
+    opts = _ffi.make_step_opts(PK, cond, flags) if (PK is not None or cond is not None or flags) else None
     xh, mu, lv = outs
     _ffi.check(_ffi.lib().psvae_train_step_f32(
         C.byref(ws.dims), _ffi.ptr(x), C.byref(P), _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state),
         C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv), beta, _ffi.ptr(grad_loss), C.byref(G),
-        _ffi.ptr(loss3), _ffi.ptr(ws.scratch), phases, _ffi.stream_ptr()), "train_step")
+        _ffi.ptr(loss3), _ffi.ptr(ws.scratch), phases, C.byref(opts) if opts is not None else None,
+        _ffi.stream_ptr()), "train_step")
+
+
+def last_step_launches() -> int:
+    """kernel launches issued by this thread's most recent train_step call"""
+    return int(_ffi.lib().psvae_last_step_launches())
+
+
+def transpose_params(ws: Workspace, params: Sequence[torch.Tensor], params_kmajor: Sequence[torch.Tensor]) -> None:
+    """(re)make the k-major weight copies: params_kmajor[2k] <- params[2k]^T (one launch)"""
+    P, PK = _ffi.make_params(params), _ffi.make_params(params_kmajor)
+    _ffi.check(_ffi.lib().psvae_transpose_params_f32(C.byref(ws.dims), C.byref(P), C.byref(PK), _ffi.stream_ptr()),
+               "transpose_params")
 
 
 def tune_train_step(ws: Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], outs, loss3,
-                    iters: int = 10) -> str:
+                    iters: int = 10, params_kmajor: Optional[Sequence[torch.Tensor]] = None) -> str:
     """Autotune the fused step's launch plan for this (B, D, Z) (psvae_tune_train_step_f32): times the whole step
-    under each candidate plan on the current stream -- a second or two -- and keeps the fastest for every later
-    train_step call of this process.  Overwrites ws.acts / outs / grads / loss3.  Returns the plan's text form."""
+    under each candidate plan on the current stream -- a few seconds -- and keeps the fastest for every later
+    train_step call of this process, but only if it beats the heuristic plan by a margin in the same session.
+    Overwrites ws.acts / outs / grads / loss3.  Returns the plan's text form."""
     P = _ffi.make_params(params)
     G = _ffi.make_grads(grads)
+    PK = _ffi.make_params(params_kmajor) if params_kmajor is not None else None
+    opts = _ffi.make_step_opts(PK) if PK is not None else None
     xh, mu, lv = outs
     _ffi.check(_ffi.lib().psvae_tune_train_step_f32(
         C.byref(ws.dims), _ffi.ptr(x), C.byref(P), C.byref(ws.acts_c), _ffi.ptr(xh), _ffi.ptr(mu), _ffi.ptr(lv),
-        C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), iters, _ffi.stream_ptr()), "tune_train_step")
+        C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), iters, C.byref(opts) if opts is not None else None,
+        _ffi.stream_ptr()), "tune_train_step")
     return describe_plan(ws)
 
 
-def tune_or_load_plan(ws: Workspace, x, params, grads, outs, loss3, iters: int = 10, cache_path: Optional[str] = None) -> str:
-    """tune_train_step with a small JSON cache (default: $PSVAE_PLAN_CACHE, none if unset) keyed by GPU name and
-    (B, D, Z): a production job pays the few seconds of tuning once per shape and machine type."""
+PLAN_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)),
+                                       "launch_plans.json")
+
+
+def plan_key(ws: Workspace) -> str:
+    """plans are keyed by GPU architecture + CU count and the batch shape (the marketing name is not stable)"""
+    pr = torch.cuda.get_device_properties(ws.device)
+    arch = getattr(pr, "gcnArchName", "gpu").split(":")[0]
+    return f"{arch}/{pr.multi_processor_count}cu|{ws.B}x{ws.D}x{ws.Z}"
+
+
+def _read_plans(path):
     import json, os
-    cache_path = cache_path or os.environ.get("PSVAE_PLAN_CACHE")
-    key = f"{torch.cuda.get_device_name(ws.device)}|{ws.B}x{ws.D}x{ws.Z}"
-    cache = {}
-    if cache_path and os.path.exists(cache_path):
+    if path and os.path.exists(path):
         try:
-            cache = json.load(open(cache_path))
+            return json.load(open(path))
         except (OSError, ValueError):
-            cache = {}
-    if key in cache:
-        try:
-            set_plan(ws, cache[key])
-            return describe_plan(ws)
-        except _ffi.PsvaeError:
-            pass  # written by another library version: tune again
-    plan = tune_train_step(ws, x, params, grads, outs, loss3, iters=iters)
+            pass
+    return {}
+
+
+def load_committed_plan(ws: Workspace, cache_path: Optional[str] = None) -> Optional[str]:
+    """install the plan recorded for this GPU model and (B, D, Z): $PSVAE_PLAN_CACHE / cache_path first, then the
+    committed pseudo_speaker_vae_amd/launch_plans.json.  Returns its text form, or None if there is no entry."""
+    import os
+    key = plan_key(ws)
+    for path in (cache_path or os.environ.get("PSVAE_PLAN_CACHE"), PLAN_FILE):
+        text = _read_plans(path).get(key)
+        if text:
+            try:
+                set_plan(ws, text)
+                return describe_plan(ws)
+            except _ffi.PsvaeError:
+                continue  # written by another library version
+    return None
+
+
+def tune_or_load_plan(ws: Workspace, x, params, grads, outs, loss3, iters: int = 10, cache_path: Optional[str] = None,
+                      force: bool = False, params_kmajor=None, step_kwargs=None) -> str:
+    """The recorded plan for this GPU model and shape if there is one (so every run uses the SAME plan); else -- or
+    with force=True -- tune_train_step, and remember the result in cache_path / $PSVAE_PLAN_CACHE when one is given."""
+    import json, os
+    if not force:
+        got = load_committed_plan(ws, cache_path)
+        if got is not None:
+            return got
+    plan = tune_train_step(ws, x, params, grads, outs, loss3, iters=iters, params_kmajor=params_kmajor)
+    cache_path = cache_path or os.environ.get("PSVAE_PLAN_CACHE")
     if cache_path:
-        cache[key] = plan
+        cache = _read_plans(cache_path)
+        cache[plan_key(ws)] = plan
         tmp = f"{cache_path}.tmp{os.getpid()}"
         with open(tmp, "w") as f:
             json.dump(cache, f, indent=1)
@@ -272,3 +324,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9
     _ffi.check(_ffi.lib().psvae_adam_step_f32(_ffi.ptr(param), _ffi.ptr(grad), _ffi.ptr(exp_avg), _ffi.ptr(exp_avg_sq),
                                               n, step, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
                                               _ffi.stream_ptr()), "adam_step")
+
+
+def adam_step_dev(layout: "_ffi.AdamDev", state: torch.Tensor, betas=(0.9, 0.999), eps: float = 1e-8,
+                  weight_decay: float = 0.0, grad_scale: float = 1.0):
+    """psvae_adam_step_dev_f32: Adam with {lr, step} on the device (state: 24-byte uint8 tensor holding a
+    psvae_adam_state) that also maintains the k-major weight copies; graph-capturable."""
+    _ffi.check(_ffi.lib().psvae_adam_step_dev_f32(C.byref(layout), _ffi.ptr(state), betas[0], betas[1], eps,
+                                                  weight_decay, grad_scale, _ffi.stream_ptr()), "adam_step_dev")

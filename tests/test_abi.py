@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.psvae_version() == 1
+    assert lib.psvae_version() == 2
     assert b"NULL" in lib.psvae_strerror(-1)
     assert lib.psvae_strerror(0) == b"ok"
 
@@ -71,7 +71,7 @@ def test_launch_plan_text_roundtrip_and_errors(lib):
     assert lib.psvae_set_plan(C.byref(d), None) == -1
     assert lib.psvae_set_plan(C.byref(d), b"untuned") == 0
     assert lib.psvae_describe_plan(C.byref(d), buf, 1024) == 0 and buf.value == b"untuned"
-    assert lib.psvae_tune_train_step_f32(C.byref(d), None, None, None, None, None, None, None, None, None, 0, None) == -4
+    assert lib.psvae_tune_train_step_f32(C.byref(d), None, None, None, None, None, None, None, None, None, 0, None, None) == -4
 
 
 def test_header_is_plain_c_and_links_against_the_library(tmp_path, lib):
@@ -96,7 +96,14 @@ int main(void) {
     if (psvae_describe_plan(&d, buf, sizeof buf) != 0 || strcmp(buf, "untuned") != 0) return 4;
     if (psvae_set_plan(&d, "garbage") != PSVAE_ERR_ARG) return 5;
     if (psvae_train_step_f32(&d, NULL, NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, NULL, 1.0f, NULL, NULL, NULL, NULL,
-                             PSVAE_PHASE_ALL, NULL) != PSVAE_ERR_NULL) return 6;
+                             PSVAE_PHASE_ALL, NULL, NULL) != PSVAE_ERR_NULL) return 6;
+    {
+        psvae_step_opts o = {NULL, NULL, PSVAE_COS_LOSS};
+        psvae_adam_state st = {1e-3, 0, 0u, 0u};
+        if (o.flags != 2u || sizeof st != 24 || psvae_last_step_launches() != 0) return 7;
+        if (psvae_adam_step_dev_f32(NULL, NULL, 0.9, 0.999, 1e-8, 0.0, 1.0, NULL) != PSVAE_ERR_NULL) return 8;
+        if (psvae_transpose_params_f32(&d, NULL, NULL, NULL) != PSVAE_ERR_NULL) return 9;
+    }
     printf("c abi ok\n");
     return 0;
 }

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import check_masks, masks_of  # noqa: E402
 from helpers import GOLDEN, REL_TOL, assert_close, load
 from oracle import psvae_oracle as O
 
@@ -75,13 +76,17 @@ def test_training_step_matches_oracle(variant):
     mod.model._philox_offset = 0
     out = mod.training_step((x.to(DEV), y.to(DEV)), 0)
     out["loss"].backward()                                       # what Lightning does after lightning.py:131
-    eps = torch.from_numpy(O.philox_normal(B * Z, 21, 0).reshape(B, Z))
-    losses, grads, acts, _ = O.train_step(p, x, eps, 0.6, variant == "norm", variant == "cos")
+    ctx = mod.model._scratch_cache.last_ctx()                    # the step's saved activations (alive while `out` is)
+    eps = ctx.acts["eps"].cpu()                                  # the epsilon the device drew: the oracle gets the same
+    assert_close(eps, O.philox_normal(B * Z, 21, 0).reshape(B, Z), 1e-5, "device Philox stream vs oracle")
+    masks = masks_of(ctx.acts)
+    losses, grads, acts, _ = O.train_step(p, x, eps, 0.6, variant == "norm", variant == "cos", masks=masks)
+    check_masks(masks, acts)
     assert abs(float(out["loss"]) - float(losses["total"])) < REL_TOL
     assert abs(float(mod.logged["train_recon_loss"]) - float(losses["recon"])) < REL_TOL
     assert abs(float(mod.logged["train_kl_loss"]) - float(losses["kl"])) < REL_TOL
     for k, q in zip(O.PARAM_KEYS, mod.model.ordered_params()):
-        assert_close(q.grad.cpu(), grads[k], 2e-4, "grad " + k)  # eps differs in the last ulp (Box-Muller on device)
+        assert_close(q.grad.cpu(), grads[k], REL_TOL, "grad " + k)
     with torch.no_grad():
         v = mod.validation_step((x.to(DEV), y.to(DEV)), 0)
     assert "val_loss" in mod.logged and torch.isfinite(v["loss"])
@@ -99,8 +104,22 @@ def test_training_step_with_classifier_branch():
     out["loss"].backward()
     assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in mod.parameters())
     assert {"train_loss", "train_recon_loss", "train_kl_loss", "train_classifier_loss", "train_classifier_acc"} <= set(mod.logged)
-    # cross-check the VAE part of the gradient against torch autograd on the oracle's forward
-    p = {k: v.detach().cpu().clone().requires_grad_() for k, v in mod.model.state_dict().items()}
+    # cross-check loss and VAE gradients against the oracle's step with the same head (CPU autograd for the head)
+    ctx = mod.model._scratch_cache.last_ctx()
+    eps = ctx.acts["eps"].cpu()
+    p = {k: v.detach().cpu() for k, v in zip(O.PARAM_KEYS, mod.model.ordered_params())}
+    lins = [m for m in mod.classifier.layers if isinstance(m, torch.nn.Linear)]
+    layers = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in lins]
+    masks = masks_of(ctx.acts)
+    losses, vgrads, cgrads = O.train_step_with_classifier(p, layers, x.cpu(), y.cpu(), eps, 1.0, 0.3, masks=masks)
+    check_masks(masks, losses["acts"])
+    assert abs(float(out["loss"]) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
+    assert abs(float(mod.logged["train_classifier_loss"]) - float(losses["ce"])) <= REL_TOL
+    for k, q in zip(O.PARAM_KEYS, mod.model.ordered_params()):
+        assert_close(q.grad.cpu(), vgrads[k], REL_TOL, "grad " + k)
+    for (gW, gb), lin in zip(cgrads, lins):
+        assert_close(lin.weight.grad.cpu(), gW, REL_TOL, "classifier dW")
+        assert_close(lin.bias.grad.cpu(), gb, REL_TOL, "classifier db")
 
 
 @pytest.mark.parametrize("name", ["langevin_d256_z64_n8_t5", "langevin_d256_z64_n8_t5_lin"])
@@ -191,11 +210,14 @@ def test_engine_graph_equals_eager_and_matches_oracle():
     # last step against the oracle with the same epsilon stream
     eps = torch.from_numpy(O.philox_normal(B * Z, 0, 4 * (B * Z // 4)).reshape(B, Z))
     p = O.init_params(D, Z, 0)
-    masks = {k: (e1.ws.acts[k] > 0).cpu() for k in ("h1m", "h2m", "h1s", "h2s", "d1", "d2")}
-    losses, grads, _, _ = O.train_step(p, x, eps, 1.0, masks=masks)
+    eps_dev = e1.ws.acts["eps"].cpu()
+    assert_close(eps_dev, eps, 1e-5, "device Philox stream vs oracle")
+    masks = masks_of(e1.ws.acts)
+    losses, grads, oacts, _ = O.train_step(p, x, eps_dev, 1.0, masks=masks)
+    check_masks(masks, oacts)
     assert abs(float(e1.loss3[0]) - float(losses["total"])) < REL_TOL
     for k, gd in zip(O.PARAM_KEYS, e1.grads):
-        assert_close(gd.cpu(), grads[k], 2e-4, "grad " + k)
+        assert_close(gd.cpu(), grads[k], REL_TOL, "grad " + k)
 
 
 def test_engine_adam_training_reduces_loss_and_matches_oracle_step():
@@ -209,10 +231,11 @@ def test_engine_adam_training_reduces_loss_and_matches_oracle_step():
     eng.forward_backward(xd)
     eps = eng.ws.acts["eps"].cpu()
     p = O.init_params(D, Z, 0)
-    masks = {k: (eng.ws.acts[k] > 0).cpu() for k in ("h1m", "h2m", "h1s", "h2s", "d1", "d2")}
-    _, grads, _, _ = O.train_step(p, x, eps, 1.0, masks=masks)
+    masks = masks_of(eng.ws.acts)
+    _, grads, oacts, _ = O.train_step(p, x, eps, 1.0, masks=masks)
+    check_masks(masks, oacts)
     for k, gd in zip(O.PARAM_KEYS, eng.grads):
-        assert_close(gd.cpu(), grads[k], 2e-4, "grad " + k)
+        assert_close(gd.cpu(), grads[k], REL_TOL, "grad " + k)
     gpu_grads = [gd.cpu().clone() for gd in eng.grads]
     eng.optimizer_step()
     # Adam divides by sqrt(v): entries with |g| ~ eps amplify last-bit gradient noise, so the fused
@@ -246,6 +269,9 @@ def test_conditional_model_matches_concat_definition():
     t_ref.backward()
     assert_close(xh.detach().cpu(), a["x_hat"].detach(), REL_TOL, "x_hat")
     assert abs(float(total) - float(t_ref)) < REL_TOL
+    # 3e-4 below: the reference side is torch autograd on the literal concat, so ReLU masks cannot be aligned; one
+    # kink flip moves a dW row by O(1/sqrt(B)) (B = 96).  The closed-form comparison at equal masks is at 1e-4 in
+    # test_gpu_fused_step.py::test_fused_step_conditional_matches_oracle.
     for blk, n_in in (("encoder_mu", D), ("encoder_sigma", D), ("decoder", Z)):
         gW = pc[f"{blk}.0.weight"].grad
         assert_close(dict(m.named_parameters())[f"{blk}.0.weight"].grad.cpu(), gW[:, :n_in], 3e-4, blk + " W")
@@ -302,11 +328,14 @@ def test_model_tune_then_training_step_still_matches_oracle():
     x, eps = torch.randn(B, D), torch.randn(B, Z)
     total, recon, kl, xh, mu, lv = m.elbo_step(x.cuda(), beta=0.8, eps=eps.cuda())
     total.backward()
-    losses, ograds, acts, _ = O.train_step(p, x, eps, 0.8)
+    from helpers import check_masks, masks_of
+    masks = masks_of(m._scratch_cache.last_ctx().acts)
+    losses, ograds, acts, _ = O.train_step(p, x, eps, 0.8, masks=masks)
+    check_masks(masks, acts)
     assert abs(float(total) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
     assert_close(xh.detach().cpu(), acts["x_hat"], REL_TOL, "x_hat")
     for k, t in zip(O.PARAM_KEYS, m.ordered_params()):
-        assert_close(t.grad.cpu(), ograds[k], 5e-4, "grad " + k)  # no mask alignment here: allow a ReLU-kink flip
+        assert_close(t.grad.cpu(), ograds[k], REL_TOL, "grad " + k)
 
 
 def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
@@ -326,11 +355,14 @@ def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
         m.zero_grad(set_to_none=True)
         total, recon, kl, xh, mu, lv = m.elbo_step(x.cuda(), beta=1.3, eps=eps.cuda())
         (total * scale).backward()
-        losses, ograds, acts, _ = O.train_step(p, x, eps, 1.3, go=scale)
+        from helpers import check_masks, masks_of
+        masks = masks_of(m._scratch_cache.last_ctx().acts)
+        losses, ograds, acts, _ = O.train_step(p, x, eps, 1.3, go=scale, masks=masks)
+        check_masks(masks, acts)
         assert abs(float(total) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
         assert_close(mu.cpu(), acts["mu"], REL_TOL, "mu")
         for k, t in zip(O.PARAM_KEYS, m.ordered_params()):
-            assert_close(t.grad.cpu(), ograds[k], 5e-4, f"scale {scale} grad {k}")
+            assert_close(t.grad.cpu(), ograds[k], REL_TOL, f"scale {scale} grad {k}")
     m.zero_grad(set_to_none=True)
     with torch.no_grad():
         total, *_ = m.elbo_step(torch.randn(B, D, device="cuda:0"))
@@ -395,6 +427,8 @@ def test_training_step_classifier_branch_fused_equals_torch_ops():
     lf, gf = run(True)
     lt, gt = run(False)
     assert abs(lf - lt) <= 1e-5 * max(1.0, abs(lt))
+    # two GPU paths against each other (not an oracle parity assert): 2e-4 because the torch-op branch gets its
+    # cross-entropy gradient from ATen (different fp32 rounding feeds the same backward GEMMs; ReLU masks are not pinned)
     for a, b in zip(gf, gt):
         assert_close(a.cpu(), b.cpu(), 2e-4, "fused vs torch-op classifier branch")
 
@@ -646,7 +680,7 @@ def test_training_step_consistency_fused_node_equals_separate_nodes(with_clf):
         assert abs(logf[k] - logt[k]) <= 1e-5 * max(1.0, abs(logt[k])), k
     for a, b in zip(gf, gt):
         assert (a is None) == (b is None)
-        if a is not None:
+        if a is not None:  # (two GPU paths, not an oracle assert: see the note in the classifier-branch test above)
             assert_close(a.cpu(), b.cpu(), 2e-4, "fused two-head node vs separate nodes")
     assert all(q.grad is None for q in mod.consistency_classifier.parameters())
     mod.zero_grad(set_to_none=True)

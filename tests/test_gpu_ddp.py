@@ -1,0 +1,165 @@
+"""The gradient exchange (DDPStrategy, /root/reference/ps_vae/training.py:78) on the GPU.
+
+(1) TrainEngine with a 1-rank RCCL group on the box's single GPU: every data-parallel mode -- eager phase split with
+    two bucketed all-reduces, captured step + one all-reduce, two captured halves around the collectives, collective(s)
+    captured inside the step's graph -- must leave gradients, loss scalars and the Philox state bit-identical to the
+    engine without a group (ncclAvg over one rank is the identity; what is under test is that every bucket is reduced
+    after the kernels that write it, and that nothing is skipped or reordered).
+(2) TWO ranks sharing the one GPU over gloo (RCCL refuses two ranks on one device): each rank's TrainEngine takes half
+    of the rows; after the exchange both hold the same averaged gradients, equal to one engine on the full batch
+    (mean-of-shards identity) with the same epsilon rows (world-size-invariant Philox interleave).
+"""
+import os
+import socket
+
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+D, Z, B = 256, 64, 512
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield dist.group.WORLD
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _same(e_ref, e, what):
+    torch.cuda.synchronize()
+    assert torch.equal(e_ref.flat_grads, e.flat_grads), what + ": gradients / loss scalars differ"
+    assert torch.equal(e_ref.rng_state, e.rng_state), what + ": Philox state differs"
+    assert torch.equal(e_ref.ws.acts["eps"], e.ws.acts["eps"]), what + ": epsilon differs"
+
+
+@pytest.mark.parametrize("mode", ["eager_split", "graph_then_allreduce", "two_graphs", "in_graph", "in_graph_overlap"])
+def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group, mode):
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    x = torch.randn(B, D, device=DEV)
+    ref = TrainEngine(D, Z, B, device=DEV, seed=7, beta=0.9)
+    eng = TrainEngine(D, Z, B, device=DEV, seed=7, beta=0.9, process_group=nccl_group)
+    assert eng.world == 1 and eng.averager is not None and eng.averager.backend == "nccl"
+    warm = 0
+    if mode == "eager_split":
+        step = lambda: eng.forward_backward(x)
+    elif mode == "graph_then_allreduce":
+        eng.capture(x)
+        warm, step = 2, eng.replay
+    elif mode == "two_graphs":
+        eng.capture_ddp(x)
+        warm, step = 2, eng.replay_ddp
+    else:
+        eng.capture_with_collective(x, overlap=(mode == "in_graph_overlap"))
+        warm, step = 3, eng.replay
+    for _ in range(warm):  # the captures warm up with real steps: keep the reference's Philox state in step
+        ref.forward_backward(x)
+    for it in range(3):
+        ref.forward_backward(x)
+        step()
+        _same(ref, eng, f"{mode} step {it}")
+    assert float(eng.loss3[0]) == float(ref.loss3[0]) and torch.isfinite(eng.flat_grads).all()
+
+
+def test_one_rank_rccl_optimizer_after_the_exchange(nccl_group):
+    """the whole data-parallel iteration: captured step, all-reduce, fused Adam -- same parameters as without a group"""
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    x = torch.randn(B, D, device=DEV)
+    ref = TrainEngine(D, Z, B, device=DEV, seed=2)
+    eng = TrainEngine(D, Z, B, device=DEV, seed=2, process_group=nccl_group)
+    eng.capture(x)
+    ref.capture(x)
+    for _ in range(3):
+        ref.replay(); ref.optimizer_step()
+        eng.replay(); eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.equal(ref.flat_params, eng.flat_params) and torch.equal(ref.flat_params_t, eng.flat_params_t)
+
+
+def _two_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pseudo_speaker_vae_amd.engine import TrainEngine
+        torch.cuda.set_device(0)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, D, generator=g)
+        rows = slice(rank * B // world, (rank + 1) * B // world)
+        xs = x[rows].to(DEV)
+        eng = TrainEngine(D, Z, B // world, device=DEV, seed=5, beta=0.8, process_group=dist.group.WORLD)
+        out = {}
+        eng.forward_backward(xs)                       # eager: phase split + two bucketed all-reduces
+        torch.cuda.synchronize()
+        out["eager_grads"] = eng.flat_grads.cpu().clone()
+        out["eager_eps"] = eng.ws.acts["eps"].cpu().clone()
+        eng.capture(xs)                                # 2 warm-up steps (local) + capture
+        eng.replay()                                   # captured step, then ONE all-reduce of the flat buffer
+        torch.cuda.synchronize()
+        out["graph_grads"] = eng.flat_grads.cpu().clone()
+        out["graph_eps"] = eng.ws.acts["eps"].cpu().clone()
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        out["params"] = eng.flat_params.cpu().clone()
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_gloo_average_like_one_full_batch_engine():
+    import torch.multiprocessing as mp
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # both ranks hold the same averaged gradients and, after Adam, the same parameters
+    for key in ("eager_grads", "graph_grads", "params"):
+        assert torch.equal(res[0][key], res[1][key]), key
+    # ... equal to ONE engine on the full batch at the same Philox positions
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, D, generator=g).to(DEV)
+    full = TrainEngine(D, Z, B, device=DEV, seed=5, beta=0.8)
+    full.forward_backward(x)
+    torch.cuda.synchronize()
+    eps_full = full.ws.acts["eps"].cpu()
+    assert torch.equal(torch.cat([res[0]["eager_eps"], res[1]["eager_eps"]]), eps_full)  # W-invariant epsilon stream
+    lay = full.layout
+    for k, (o, s) in zip(full.keys, zip(lay.offsets, lay.shapes)):
+        n = s.numel()
+        assert_close(res[0]["eager_grads"][o:o + n], full.flat_grads[o:o + n].cpu(), 2e-5, "mean of shard grads " + k)
+    lo = lay.loss_offset
+    assert_close(res[0]["eager_grads"][lo:lo + 3], full.flat_grads[lo:lo + 3].cpu(), 2e-6, "averaged loss scalars")
+    for _ in range(3):          # the ranks' capture ran 2 warm-ups + the replayed step = full-batch steps 2..4
+        full.forward_backward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([res[0]["graph_eps"], res[1]["graph_eps"]]), full.ws.acts["eps"].cpu())
+    for k, (o, s) in zip(full.keys, zip(lay.offsets, lay.shapes)):
+        n = s.numel()
+        assert_close(res[0]["graph_grads"][o:o + n], full.flat_grads[o:o + n].cpu(), 2e-5, "captured: shard mean " + k)

@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (GOLDEN, REL_TOL, assert_close, check_grads_against_fixture, fixture_params, load,
-                     step_fixtures)
+from helpers import (GOLDEN, MASK_KEYS, REL_TOL, assert_close, check_grads_against_fixture, check_masks,
+                     fixture_params, load, step_fixtures)
 from oracle import psvae_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -38,21 +38,6 @@ def run_step(ops, p, x, eps, beta, normalize, cos, go=None, seed=None):
     masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
     return dict(x_hat=xh.cpu(), mu=mu.cpu(), logvar=lv.cpu(), z=ws.acts["z"].cpu(), eps=ws.acts["eps"].cpu(),
                 loss3=loss3.cpu(), grads={k: g.cpu() for k, g in zip(O.PARAM_KEYS, grads)}, ws=ws, masks=masks)
-
-
-MASK_KEYS = ("h1m", "h2m", "h1s", "h2s", "d1", "d2")
-
-
-def check_masks(gpu_masks, oracle_acts):
-    """ReLU masks of the HIP path may differ from the oracle's only at activations within fp32
-    rounding of zero (the ReLU kink), and only for a vanishing fraction of elements."""
-    for k in MASK_KEYS:
-        ref = oracle_acts[k]
-        diff = gpu_masks[k] != (ref > 0)
-        n = int(diff.sum())
-        assert n <= max(2, 2e-5 * ref.numel()), f"{k}: {n} mask flips"
-        if n:
-            assert float(ref[diff].abs().max()) <= 2e-5 * float(ref.abs().max()), f"{k}: flip at a non-tiny activation"
 
 
 @pytest.mark.parametrize("path", step_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
@@ -230,12 +215,16 @@ def test_fused_train_step_matches_unfused_path_and_oracle(ops, D, Z, B):
     ops.train_step(ws, x.to(DEV), params, grads, outs, loss3, beta=0.9, eps=eps.to(DEV),
                    grad_loss=torch.tensor([go], device=DEV))
     torch.cuda.synchronize()
-    assert_close(outs[0].cpu(), ref["x_hat"], 1e-6, "x_hat")
-    assert_close(loss3.cpu(), ref["loss3"], 1e-6, "loss3")
-    for k, g in zip(O.PARAM_KEYS, grads):
-        assert_close(g.cpu(), ref["grads"][k], 2e-6, "fused vs unfused grad " + k)
+    # (the fused step sums the heads' products and decoder.0's dgrad as 8 partial products in fixed order: the same
+    # numbers to fp32 rounding, not bit for bit)
+    assert_close(outs[0].cpu(), ref["x_hat"], 5e-6, "x_hat")
+    assert_close(loss3.cpu(), ref["loss3"], 5e-6, "loss3")
     masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
-    losses, ograds, _, _ = O.train_step(p, x, eps, 0.9, go=go, masks=masks)
+    if all(torch.equal(masks[k], ref["masks"][k]) for k in MASK_KEYS):  # (a ReLU-kink flip moves a whole dW row)
+        for k, g in zip(O.PARAM_KEYS, grads):
+            assert_close(g.cpu(), ref["grads"][k], 2e-5, "fused vs unfused grad " + k)
+    losses, ograds, oacts, _ = O.train_step(p, x, eps, 0.9, go=go, masks=masks)
+    check_masks(masks, oacts)
     for i, k in enumerate(("total", "recon", "kl")):
         assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
     for k, g in zip(O.PARAM_KEYS, grads):
@@ -264,7 +253,8 @@ def test_wgrad_cross_workgroup_split_matches_oracle(ops, D, Z, B):
     finally:
         _ffi.lib().psvae_debug_force_wgrad_split(0)
     assert _ffi.lib().psvae_debug_force_wgrad_split(5) == -4
-    _, ograds, _, _ = O.train_step(p, x, eps, 1.3, masks=results[1][1])
+    _, ograds, oacts, _ = O.train_step(p, x, eps, 1.3, masks=results[1][1])
+    check_masks(results[1][1], oacts)
     for S, (grads, _) in results.items():
         for k, g, g1 in zip(O.PARAM_KEYS, grads, results[1][0]):
             assert_close(g, g1, 5e-6, f"S={S} vs S=1 grad {k}")
@@ -294,7 +284,8 @@ def test_autotuned_launch_plan_keeps_results(ops):
     ops.train_step(ws, x.to(DEV), params, grads, outs, loss3, beta=0.7, eps=eps.to(DEV))
     torch.cuda.synchronize()
     masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
-    losses, ograds, _, _ = O.train_step(p, x, eps, 0.7, masks=masks)
+    losses, ograds, oacts, _ = O.train_step(p, x, eps, 0.7, masks=masks)
+    check_masks(masks, oacts)
     for i, k in enumerate(("total", "recon", "kl")):
         assert abs(float(loss3[i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
     for k, g in zip(O.PARAM_KEYS, grads):
