@@ -219,6 +219,16 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             if (c + s < cend) mma(s);
     }
 
+    // second stage (see below): its weight fragments are requested NOW, so that they land while the k-slices are being
+    // reduced through LDS (the main loop's fragment ring is dead from here on: the registers are free)
+    f32x4 b4[S2 ? 4 : 1][4];
+    if (S2 && d.B2 != nullptr) {
+        const float* __restrict__ W2 = d.B2 + (size_t)n0 * d.Z2;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b4[c2][t] = ldg<f32x4>(W2 + (size_t)(16 * c2 + 4 * q + t) * d.Z2 + 4 * r);
+    }
     // ---- epilogue: k-slices meet in LDS ([KS][BM][BN+4]), summed in fixed order; whole rows leave ----
     constexpr int SC = BN + 4;
     float* __restrict__ Cs = smem + ks * (BM * SC);
@@ -378,11 +388,13 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             const float* __restrict__ W2 = d.B2 + (size_t)n0 * Z2;
             float* __restrict__ slab = d.slab2 + (size_t)tn * M * Z2;
             for (int zc = 0; zc < Z2; zc += 64) {
-                f32x4 a4[4], b4[4][4];
+                f32x4 a4[4];
+                if (zc > 0) {  // (Z = 128: the second column group's fragments are fetched here)
 #pragma unroll
-                for (int c2 = 0; c2 < 4; ++c2)
+                    for (int c2 = 0; c2 < 4; ++c2)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b4[c2][t] = ldg<f32x4>(W2 + (size_t)(16 * c2 + 4 * q + t) * Z2 + zc + 4 * r);
+                        for (int t = 0; t < 4; ++t) b4[c2][t] = ldg<f32x4>(W2 + (size_t)(16 * c2 + 4 * q + t) * Z2 + zc + 4 * r);
+                }
 #pragma unroll
                 for (int c2 = 0; c2 < 4; ++c2) a4[c2] = *reinterpret_cast<const f32x4*>(smem + (16 * wave + r) * SC + 16 * c2 + 4 * q);
                 f32x4 acc2[4];
@@ -778,17 +790,17 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     bool many_small = c0 == 8 && c1 == 8;  // 16x32 tiles: light workgroups, meant to be co-resident (see finalize_batch)
     const bool cap = b.hint_cap == 1 || (b.hint_cap == 0 && cap_default && b.total_tiles > 256 && !many_small);
     if (cap && lds < 82 * 1024) lds = 82 * 1024;
+    bool stage2 = false;  // a problem with a second stage (GemmDesc::B2): only the dedicated <.., 6, true> kernels run it
+    for (int i = 0; i < b.n; ++i) stage2 = stage2 || b.d[i].B2 != nullptr;
     {   // decode-sized: >= 4 tiles per CU, one config, no weight gradients, no k split across workgroups
         static const int persist_min = env_int("PSVAE_PERSIST_MIN", 1024);
-        bool plain = c0 == c1 && b.xcd_remap == 0;
+        bool plain = c0 == c1 && b.xcd_remap == 0 && !stage2;
         for (int i = 0; i < b.n; ++i) plain = plain && b.d[i].kind != GK_TN && b.d[i].ksplit == 1;
         if (plain && persist_min > 0 && b.total_tiles >= persist_min) {
             if (c0 == 7) return launch_persistent<7>(b, lds, stream);
             if (c0 == 6) return launch_persistent<6>(b, lds, stream);
         }
     }
-    bool stage2 = false;
-    for (int i = 0; i < b.n; ++i) stage2 = stage2 || b.d[i].B2 != nullptr;
     if (stage2) {
         for (int i = 0; i < b.n; ++i) {
             const GemmDesc& d = b.d[i];
@@ -811,6 +823,7 @@ hipError_t launch_gemm_batch(GemmBatch& b, int cfg, hipStream_t stream) {
     PSVAE_PAIR(8, 1); PSVAE_PAIR(8, 2); PSVAE_PAIR(8, 4); PSVAE_PAIR(8, 6);
     PSVAE_PAIR(6, 1); PSVAE_PAIR(6, 2); PSVAE_PAIR(6, 4); PSVAE_PAIR(6, 8);
     PSVAE_PAIR(2, 1); PSVAE_PAIR(2, 4); PSVAE_PAIR(2, 6); PSVAE_PAIR(2, 8);
+    PSVAE_PAIR(6, 9); PSVAE_PAIR(2, 9);  // 64 x 128 dgrad tiles beside the weight gradients (heavy two-round launches)
 #undef PSVAE_PAIR
     return hipErrorInvalidValue;
 }

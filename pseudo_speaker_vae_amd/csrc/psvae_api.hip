@@ -475,10 +475,40 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     const void* al[] = {mu, logvar, eps_in, acts->eps, acts->z, acts->d1, P[12], P[13], P[5], P[11], sc.gmu, sc.glv,
                         acts->h2m, acts->h2s};
     const bool bn_ok = reparam_linear_ok(Z, H, al, 14);
-    static const bool stage2_on = getenv("PSVAE_NO_STAGE2") == nullptr;
+    // PSVAE_STAGE2: bit 0 = the heads ride on encoder layer 1's launch, bit 1 = decoder.0's dgrad rides on decoder.2's
+    static const int stage2_mask = getenv("PSVAE_NO_STAGE2") ? 0 : (getenv("PSVAE_STAGE2") ? atoi(getenv("PSVAE_STAGE2")) : 3);
     static const bool bottleneck_on = getenv("PSVAE_NO_BOTTLENECK") == nullptr;
-    const bool fuse = stage2_on && bottleneck_on && kmajor_w && bn_ok && (Z & 63) == 0 && Z <= 128;
+    const bool fuse_ok = bottleneck_on && kmajor_w && bn_ok && (Z & 63) == 0 && Z <= 128;
+    const bool fuse_f = fuse_ok && (stage2_mask & 1), fuse = fuse_ok && (stage2_mask & 2);
     const bool all = phases == PSVAE_PHASE_ALL;
+
+    // Which backward launch carries which weight gradient (fused single-call path): slot 1 = with decoder.4's dgrad,
+    // 2 = with decoder.2's dgrad, 3 = with the encoders' layer-1 dgrad, 4 = the last launch.  A weight gradient may
+    // ride on any launch AFTER the one that produces its dY (earliest slots below); PSVAE_WSCHED="s0,..,s8" overrides.
+    static const int kEarliest[9] = {4, 3, 3, 4, 3, 3, 3, 2, 1};
+    int wslot[9] = {4, 3, 4, 4, 3, 4, 4, 2, 1};
+    {
+        static const char* env = getenv("PSVAE_WSCHED");
+        int v[9];
+        if (env && sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) == 9) {
+            int cnt[5] = {0, 1, 1, 2, 0};  // dgrad problems already in each slot
+            bool ok = true;
+            for (int k = 0; k < 9; ++k) {
+                ok = ok && v[k] >= kEarliest[k] && v[k] <= 4;
+                if (ok) ++cnt[v[k]];
+            }
+            for (int sl = 1; sl <= 4; ++sl) ok = ok && cnt[sl] <= MAX_GROUP;
+            if (ok) for (int k = 0; k < 9; ++k) wslot[k] = v[k];
+        }
+    }
+    const bool sched = fuse && all;  // (two-phase calls and the unfused sequence keep their fixed arrangement)
+    auto add_wgrads = [&](GemmBatch& b, int slot, int site) {
+        const int Mk[9] = {H, H, Z, H, H, Z, H, H, D}, Nk[9] = {D, H, H, D, H, H, Z, H, H};
+        const float* dYk[9] = {sc.dh1m, sc.dh2m, sc.gmu, sc.dh1s, sc.dh2s, sc.glv, sc.dd1, sc.dd2, sc.gy};
+        const float* Xk[9] = {x, acts->h1m, acts->h2m, x, acts->h1s, acts->h2s, acts->z, acts->d1, acts->d2};
+        for (int k = 8; k >= 0; --k)
+            if (wslot[k] == slot) add(b, wgrad(site, k, Mk[k], Nk[k], dYk[k], Xk[k]));
+    };
 
     if (phases & PSVAE_PHASE_DECODER) {
         if (kmajor_w && !km) {
@@ -498,14 +528,14 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         {
             GemmBatch b{};
             GemmDesc dm = fwd(acts->h1m, H, 1, H, acts->h2m, EPI_BIAS_RELU), ds = fwd(acts->h1s, H, 4, H, acts->h2s, EPI_BIAS_RELU);
-            if (fuse) {  // heads: slab[tn] = relu-tile(h2) * W3^T rows of that tile
+            if (fuse_f) {  // heads: slab[tn] = relu-tile(h2) * W3^T rows of that tile
                 dm.B2 = WT[2]; dm.slab2 = sc.slab_mu; dm.Z2 = Z;
                 ds.B2 = WT[5]; ds.slab2 = sc.slab_lv; ds.Z2 = Z;
             }
             add(b, dm); add(b, ds);
             LAUNCH(launch(b, 1));
         }
-        if (!fuse) {
+        if (!fuse_f) {
             GemmBatch b{};
             add(b, fwd(acts->h2m, H, 2, Z, mu, EPI_BIAS));
             add(b, fwd(acts->h2s, H, 5, Z, logvar, EPI_BIAS));
@@ -514,7 +544,7 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         if (bottleneck_on && bn_ok) {
             // reparameterisation + KL partials + decoder layer 0 (K = Z) as one dedicated launch
             BnFwdArgs a{};
-            a.mu = mu; a.lv = logvar; a.S = fuse ? STAGE2_SLABS : 0;
+            a.mu = mu; a.lv = logvar; a.S = fuse_f ? STAGE2_SLABS : 0;
             a.slab_m = sc.slab_mu; a.slab_s = sc.slab_lv; a.b3m = P[5]; a.b3s = P[11];
             a.eps_in = eps_in; a.rng = rng_state; a.seed = seed; a.offset = offset; a.W = P[12]; a.bias = P[13];
             if (cond) { a.ctab = cond->tab[2]; a.gender = cond->gender; a.age = cond->age; }
@@ -559,13 +589,13 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         }
         {
             GemmBatch b{};
-            add(b, wgrad(6, 8, D, H, sc.gy, acts->d2));
+            if (sched) add_wgrads(b, 1, 6); else add(b, wgrad(6, 8, D, H, sc.gy, acts->d2));
             add(b, make_desc(GK_NN, B, H, D, sc.gy, D, P[16], H, sc.dd2, H, EPI_MASK, acts->d2));
             LAUNCH(launch(b, 6));
         }
         {
             GemmBatch b{};
-            add(b, wgrad(7, 7, H, H, sc.dd2, acts->d1));
+            if (sched) add_wgrads(b, 2, 7); else add(b, wgrad(7, 7, H, H, sc.dd2, acts->d1));
             GemmDesc d = make_desc(GK_NN, B, H, H, sc.dd2, H, P[14], H, sc.dd1, H, EPI_MASK, acts->d1);
             if (fuse) { d.B2 = P[12]; d.slab2 = sc.slab_gz; d.Z2 = Z; }  // g_z partials: masked-tile(dd1) * Wd1 rows
             add(b, d);
@@ -628,20 +658,27 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
         }
         {
             GemmBatch b{};
-            add(b, wgrad(10, 1, H, H, sc.dh2m, acts->h1m));
-            add(b, wgrad(10, 4, H, H, sc.dh2s, acts->h1s));
+            if (sched) {
+                add_wgrads(b, 3, 10);
+            } else {
+                add(b, wgrad(10, 1, H, H, sc.dh2m, acts->h1m));
+                add(b, wgrad(10, 4, H, H, sc.dh2s, acts->h1s));
+            }
             add(b, make_desc(GK_NN, B, H, H, sc.dh2m, H, P[2], H, sc.dh1m, H, EPI_MASK, acts->h1m));
             add(b, make_desc(GK_NN, B, H, H, sc.dh2s, H, P[8], H, sc.dh1s, H, EPI_MASK, acts->h1s));
             LAUNCH(launch(b, 10));
         }
         {
             GemmBatch b{};
-            add(b, wgrad(11, 0, H, D, sc.dh1m, x));
-            add(b, wgrad(11, 3, H, D, sc.dh1s, x));
-            if (fuse) {  // the Z-sized weight gradients ride along (their own launches sat on the launch floor)
-                add(b, wgrad(11, 2, Z, H, sc.gmu, acts->h2m));
-                add(b, wgrad(11, 5, Z, H, sc.glv, acts->h2s));
-                if (all) add(b, wgrad(11, 6, H, Z, sc.dd1, acts->z));
+            if (sched) {
+                add_wgrads(b, 4, 11);
+            } else {
+                add(b, wgrad(11, 0, H, D, sc.dh1m, x));
+                add(b, wgrad(11, 3, H, D, sc.dh1s, x));
+                if (fuse) {  // the Z-sized weight gradients ride along (their own launches sat on the launch floor)
+                    add(b, wgrad(11, 2, Z, H, sc.gmu, acts->h2m));
+                    add(b, wgrad(11, 5, Z, H, sc.glv, acts->h2s));
+                }
             }
             LAUNCH(launch(b, 11));
         }
@@ -735,7 +772,9 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
             const bool has_tn = site >= 6, has_other = site != 11;
             const bool s2 = fuse && (site == 1 || site == 7);  // second-stage launches: config 6 for the non-TN problems
             for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
-                for (int o = s2 ? 3 : 0; o < (s2 ? 4 : (has_other ? (has_tn ? 5 : 7) : 1)) && rc == 0; ++o)
+                for (int o = s2 ? 3 : 0; o < (s2 ? 4 : (has_other ? 7 : 1)) && rc == 0; ++o) {
+                    // beside weight gradients only the compiled mixed pairs exist: <tn, 9> for tn in {2, 6}, never 7
+                    if (has_tn && has_other && (ot_c[o] == 7 || (ot_c[o] == 9 && tn_c[a] != 2 && tn_c[a] != 6))) continue;
                     for (int ks = 1; ks <= (has_tn ? WGRAD_SMAX : 1) && rc == 0; ks *= 2)
                         for (int capv = 1; capv <= 2 && rc == 0; ++capv)
                             for (int rm = 1; rm <= 2 && rc == 0; ++rm) {
@@ -754,6 +793,7 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
                                     best = p;
                                 }
                             }
+                }
         }
     }
     // the search keeps a candidate on one short measurement: confirm the winner against the heuristic plan on the

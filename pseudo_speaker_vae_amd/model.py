@@ -8,7 +8,6 @@ torch.autograd.Functions; inputs must live on the GPU -- there is no CPU fallbac
 from __future__ import annotations
 
 import os
-import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -26,7 +25,15 @@ class _Buffers:
 
     def __init__(self):
         self._scratch: Dict[tuple, torch.Tensor] = {}
-        self.last_ctx = lambda: None  # weak reference to the most recent call's context (tests read its activations)
+        self.keep_last = False   # tests: keep the most recent call's context alive (its saved activations)
+        self._last = None
+
+    def remember(self, c):
+        if self.keep_last:
+            self._last = c
+
+    def last_ctx(self):
+        return self._last
 
     def scratch(self, B, D, Z, device) -> torch.Tensor:
         key = (B, D, Z, str(device))
@@ -86,7 +93,7 @@ _FUSED_AUTOGRAD = os.environ.get("PSVAE_AUTOGRAD_FUSED", "1") != "0"  # tuning s
 
 class _Ctx:
     """what backward needs, shared by both Functions"""
-    __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors", "__weakref__")
+    __slots__ = ("B", "D", "Z", "flags", "acts", "acts_c", "scratch", "dims", "cond_tensors")
 
 
 def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_tensors=None):
@@ -109,7 +116,7 @@ def _run_forward(x, eps, seed, offset, flags, params, buffers: _Buffers, cond_te
     c.cond_tensors = cond_tensors
     ws = _WsView(c)
     cond = _make_cond(cond_tensors, None)
-    buffers.last_ctx = weakref.ref(c)
+    buffers.remember(c)
     ops.vae_forward(ws, x, params, eps, seed, offset, flags, cond=cond, outs=(xh, mu, lv))
     return c, x, xh, mu, lv
 
@@ -137,7 +144,7 @@ def _run_fused_step(x, eps, seed, offset, beta, params, buffers: _Buffers, flags
     gtabs = _alloc_grads(cond_tensors[0]) if cond_tensors is not None else []
     cond = _make_cond(cond_tensors, gtabs) if cond_tensors is not None else None
     loss3 = torch.empty(3, dtype=torch.float32, device=x.device)
-    buffers.last_ctx = weakref.ref(c)
+    buffers.remember(c)
     ops.train_step(_WsView(c), x, params, grads, (xh, mu, lv), loss3, beta=beta, eps=eps, seed=seed, offset=offset,
                    cond=cond, flags=flags)
     return c, x, xh, mu, lv, loss3, grads + gtabs

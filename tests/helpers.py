@@ -37,16 +37,24 @@ def elementwise_excess(a, b, tol):
     return float((np.abs(a - b) / (tol * np.abs(b) + tol * rms)).max())
 
 
-def assert_close(a, b, tol=REL_TOL, what=""):
+def assert_close(a, b, tol=REL_TOL, what="", elementwise=None):
     """two checks: the tensor-scaled one (max error against the largest entry) and an element-wise one in which small
-    entries are NOT hidden behind the largest: |a - b| <= tol |b| + tol rms(b) for every element"""
+    entries are NOT hidden behind the largest: |a - b| <= tol |b| + tol rms(b) for every element.
+    The element-wise check is on for the parity tolerances (tol >= 5e-5: the north_star 1e-4 asserts against the
+    oracle / the reference's fixtures).  Tighter calls (1e-5 .. 1e-6) compare two fp32 evaluation ORDERS of the same
+    sum: an element that cancels to near zero legitimately differs by ~1e-7 of the summed magnitudes, which is not small
+    against |b| + rms(b) times 2e-6 -- those stay bounded against the tensor scale only; so do the bf16 emulation
+    checks (a bf16-neighbour flip is 2^-8 of the ELEMENT by construction): they pass elementwise=False."""
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     e = rel_err(a, b)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
-    x = elementwise_excess(a, b, tol)
-    assert x <= 1.0, f"{what}: element-wise error {x:.2f} x the allowed {tol:.1e} (|b| + rms(b))"
+    if elementwise is None:
+        elementwise = tol >= 5e-5
+    if elementwise:
+        x = elementwise_excess(a, b, tol)
+        assert x <= 1.0, f"{what}: element-wise error {x:.2f} x the allowed {tol:.1e} (|b| + rms(b))"
 
 
 MASK_KEYS = ("h1m", "h2m", "h1s", "h2s", "d1", "d2")

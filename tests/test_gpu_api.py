@@ -69,6 +69,7 @@ def test_training_step_matches_oracle(variant):
     hp = dict(model=dict(input_dim=D, latent_dim=Z, normalize_decoder=variant == "norm"), kl_loss_weight=0.6,
               use_cos_loss=variant == "cos", optimizer=dict(lr=1e-3), scheduler=dict(T_max=5))
     mod = PseudoSpeakerVAE(**hp).to(DEV)
+    mod.model._scratch_cache.keep_last = True
     p = O.init_params(D, Z, 4)
     x = torch.randn(B, D)
     y = torch.zeros(B, dtype=torch.long)
@@ -99,6 +100,7 @@ def test_training_step_with_classifier_branch():
     mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z),
                            classifier=dict(input_dim=Z, num_classes=3, num_layers=2, hidden_dim=64, activation="relu"),
                            classifier_loss_weight=0.3).to(DEV)
+    mod.model._scratch_cache.keep_last = True
     x, y = torch.randn(B, D, device=DEV), torch.randint(0, 3, (B,), device=DEV)
     out = mod.training_step((x, y), 0)
     out["loss"].backward()
@@ -321,6 +323,7 @@ def test_model_tune_then_training_step_still_matches_oracle():
     from helpers import assert_close, REL_TOL
     D, Z, B = 128, 32, 256
     m = VAEModel(D, Z).to("cuda:0")
+    m._scratch_cache.keep_last = True
     plan = m.tune(B, iters=2)
     assert plan.startswith("F1:")
     p = {k: v.detach().cpu() for k, v in zip(O.PARAM_KEYS, m.ordered_params())}
@@ -348,6 +351,7 @@ def test_elbo_step_autograd_uses_fused_step_and_scales_with_upstream_gradient():
     from helpers import assert_close, REL_TOL
     D, Z, B = 256, 64, 200
     m = VAEModel(D, Z).to("cuda:0")
+    m._scratch_cache.keep_last = True
     p = {k: v.detach().cpu() for k, v in zip(O.PARAM_KEYS, m.ordered_params())}
     for trial, scale in enumerate((1.0, -2.5)):
         torch.manual_seed(trial)

@@ -119,7 +119,7 @@ def _two_rank_worker(rank, world, port, q):
         eng.optimizer_step()
         torch.cuda.synchronize()
         out["params"] = eng.flat_params.cpu().clone()
-        q.put((rank, out))
+        q.put((rank, {k: v.numpy() for k, v in out.items()}))  # by value: the parent may read after this process is gone
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -139,6 +139,7 @@ def test_two_ranks_on_one_gpu_over_gloo_average_like_one_full_batch_engine():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in res.items()}
     # both ranks hold the same averaged gradients and, after Adam, the same parameters
     for key in ("eager_grads", "graph_grads", "params"):
         assert torch.equal(res[0][key], res[1][key]), key

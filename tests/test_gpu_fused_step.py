@@ -46,7 +46,7 @@ def ops():
 
 
 @pytest.mark.parametrize("D,Z,B,launches", [(256, 64, 1024, 10), (512, 128, 1024, 10), (256, 64, 37, 10),
-                                            (256, 32, 64, 12), (96, 24, 11, 13)])
+                                            (256, 64, 4096, 10), (256, 32, 64, 12), (96, 24, 11, 13)])
 def test_launch_count_and_parity_with_optimizer_maintained_kmajor_weights(ops, D, Z, B, launches):
     """cfg2 / cfg4 / cfg1 shapes: TEN launches when Z is a multiple of 64 (twelve otherwise: separate heads and
     decoder.0-dgrad launches; thirteen when Z is not a multiple of 16: no bottleneck kernel), same numbers as the oracle"""
@@ -212,7 +212,9 @@ def test_device_state_adam_keeps_both_layouts_and_counts_steps(ops):
         for k, gr in zip(O.PARAM_KEYS, grads):
             cur[k], m[k], v[k] = O.adam_step(cur[k], gr, m[k], v[k], step, lr, weight_decay=0.01)
         for k, q, qt in zip(O.PARAM_KEYS, eng.params, eng.params_t):
-            assert_close(q, cur[k], 1e-6, f"adam step {step} {k}")
+            # 2e-6: where g ~ -wd * p the kernel's fused multiply-add (one rounding of g + wd p) and the oracle's mul + add
+            # differ by an ulp of a number that nearly cancels; Adam's g / (|g| + eps) then amplifies it (measured 1.3e-6)
+            assert_close(q, cur[k], 2e-6, f"adam step {step} {k}")
             if q.dim() == 2:
                 assert torch.equal(qt, q.t()), f"k-major copy of {k} after step {step}"
         assert eng.adam_steps_done() == step
