@@ -120,6 +120,14 @@ int psvae_elbo_f32(const psvae_dims* dims, const float* x, const float* x_hat, c
                    const float* logvar, float beta, float* loss3, void* scratch, uint32_t flags,
                    void* stream);
 
+/* Gradients of the two ELBO terms of psvae_elbo_f32 w.r.t. the forward outputs (for callers that combine the terms
+ * with other losses under autograd: the multi-label / frozen-VAE branches of lightning.py:67-131):
+ *   g_xhat = *g_recon * d recon / d x_hat;   g_mu = *g_kl * mu / B;   g_logvar = *g_kl * (exp(logvar) - 1) / (2B)
+ * g_recon / g_kl: device scalars (NULL = 1).  flags: PSVAE_COS_LOSS selects the cosine reconstruction term.  2 launches. */
+int psvae_elbo_grad_f32(const psvae_dims* dims, const float* x, const float* x_hat, const float* mu,
+                        const float* logvar, const float* g_recon, const float* g_kl, float* g_xhat, float* g_mu,
+                        float* g_logvar, uint32_t flags, void* stream);
+
 /* Backward of forward (+ optionally of the ELBO): overwrites the 18 gradients.
  *   g_xhat / g_mu / g_logvar: upstream gradients of the three forward outputs (each nullable = 0);
  *   elbo != 0 adds grad_loss * d(total)/d(.) of psvae_elbo_f32 (grad_loss: device scalar, NULL = 1);

@@ -31,7 +31,7 @@ SYMBOLS = (
     "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_consistency_scratch_bytes", "psvae_consistency_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
-    "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32",
+    "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
 )
 
 
@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
     L.psvae_set_plan.restype = C.c_int
     L.psvae_train_step_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, u64, u64, vp, C.POINTER(Acts),
                                        vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, C.POINTER(StepOpts), vp]
+    L.psvae_elbo_grad_f32.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    L.psvae_elbo_grad_f32.restype = C.c_int
     L.psvae_last_step_launches.restype = C.c_int
     L.psvae_last_step_launches.argtypes = []
     L.psvae_transpose_params_f32.argtypes = [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), vp]

@@ -340,6 +340,23 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
     }
 }
 
+// d KL / d(mu, logvar) alone, scaled by a device scalar:  g_mu = g mu / B,  g_lv = g (e^lv - 1) / (2B)   (lightning.py:115-117)
+__global__ __launch_bounds__(256) void kl_grad_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                      const float* __restrict__ g_p, float* __restrict__ g_mu,
+                                                      float* __restrict__ g_lv, int64_t n, int B) {
+    const float kb = (g_p ? *g_p : 1.0f) / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        g_mu[i] = kb * mu[i];
+        g_lv[i] = 0.5f * kb * (expf(lv[i]) - 1.0f);
+    }
+}
+hipError_t launch_kl_grad(const float* mu, const float* lv, const float* g, float* g_mu, float* g_lv, int B, int Z,
+                          hipStream_t s) {
+    const int64_t n = (int64_t)B * Z;
+    hipLaunchKernelGGL(kl_grad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, mu, lv, g, g_mu, g_lv, n, B);
+    return hipGetLastError();
+}
+
 // fused-step variant: elementwise part as above (ELBO gradient always on); block 0 then finishes the
 // loss from the partial sums and advances the Philox state (every reader of rng[1] ran launches ago)
 __global__ __launch_bounds__(256) void reparam_bwd_final_kernel(

@@ -295,6 +295,19 @@ int psvae_elbo_f32(const psvae_dims* dims, const float* x, const float* x_hat, c
     return 0;
 }
 
+int psvae_elbo_grad_f32(const psvae_dims* dims, const float* x, const float* x_hat, const float* mu, const float* logvar,
+                        const float* g_recon, const float* g_kl, float* g_xhat, float* g_mu, float* g_logvar,
+                        uint32_t flags, void* stream) {
+    if (int e = check_dims(dims)) return e;
+    if (!x || !x_hat || !mu || !logvar || !g_xhat || !g_mu || !g_logvar) return PSVAE_ERR_NULL;
+    if (flags & ~PSVAE_COS_LOSS) return PSVAE_ERR_ARG;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    hipStream_t s = (hipStream_t)stream;
+    RET_IF(launch_recon_grad(x, x_hat, nullptr, nullptr, true, flags & PSVAE_COS_LOSS, false, g_recon, g_xhat, B, D, s));
+    RET_IF(launch_kl_grad(mu, logvar, g_kl, g_mu, g_logvar, B, Z, s));
+    return 0;
+}
+
 int psvae_backward_f32(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                        const psvae_acts* acts, const float* x_hat, const float* mu, const float* logvar,
                        const float* g_xhat, const float* g_mu, const float* g_logvar, int elbo, float beta,

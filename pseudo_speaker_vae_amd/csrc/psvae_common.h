@@ -245,6 +245,8 @@ hipError_t launch_recon_grad(const float* x, const float* xh, const float* ynorm
 hipError_t launch_reparam_bwd(const float* g_z, const float* mu, const float* lv, const float* eps,
                               const float* g_mu_up, const float* g_lv_up, bool elbo, float beta,
                               const float* go, float* g_mu, float* g_lv, int B, int Z, hipStream_t s);
+hipError_t launch_kl_grad(const float* mu, const float* lv, const float* g, float* g_mu, float* g_lv, int B, int Z,
+                          hipStream_t s);
 // fused-step variant of reparam_bwd: block 0 additionally finishes the loss (fixed-order sums of the KL
 // and MSE partials -> loss3 = {total, recon, kl}) and advances the device Philox state
 hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps,

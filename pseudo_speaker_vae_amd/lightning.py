@@ -203,11 +203,9 @@ class PseudoSpeakerVAE(_Base):
                     consistency_acc = (y_hat_consistency.argmax(-1) == y).float().mean()
                 self.log(f"{prefix}_consistency", consistency_acc, sync_dist=True)
                 self.log(f"{prefix}_consistency_loss", consistency_loss, sync_dist=True)
-            if self.use_cos_loss:                                          # lightning.py:110-113
-                recon = nn.functional.cosine_embedding_loss(x_hat, x, torch.ones(x.size(0), device=x.device))
-            else:
-                recon = nn.functional.mse_loss(x_hat, x, reduction="mean") / 10
-            kl = -0.5 * torch.mean(torch.sum(1 + log_sigma - mu.pow(2) - log_sigma.exp(), dim=-1))
+            # lightning.py:110-117: both ELBO terms and their gradients come from the HIP kernels (psvae_elbo_f32 /
+            # psvae_elbo_grad_f32), also in this general branch: no ATen loss on the VAE math anywhere
+            recon, kl = self.model.elbo_terms(x_hat, mu, log_sigma, x, self.use_cos_loss)
             total = (recon + self.kl_loss_weight * kl + self.classifier_loss_weight * classifier_loss
                      + self.consitency_loss_weight * consistency_loss)                  # lightning.py:119-124
         self.log(f"{prefix}_loss", total, **log_kw)                        # lightning.py:127-129 / 193-195

@@ -295,6 +295,44 @@ class ELBOClassifierStepFunction(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+class ELBOTermsFunction(torch.autograd.Function):
+    """(recon, kl) of lightning.py:110-117 from the forward outputs, on the HIP kernels (psvae_elbo_f32), differentiable
+    w.r.t. x_hat, mu and logvar (psvae_elbo_grad_f32): lets training_step branches that combine the ELBO with other
+    torch losses (multi-label heads, a frozen VAE) keep the loss itself off ATen."""
+
+    @staticmethod
+    def forward(ctx, x_hat, mu, lv, x, cos_loss, buffers):
+        import ctypes as C
+        if not x_hat.is_cuda:
+            raise _ffi.PsvaeError("the ELBO terms run on the GPU only (HIP kernels)")
+        x_hat, mu, lv, x = (t.detach().float().contiguous() for t in (x_hat, mu, lv, x))
+        B, D = x_hat.shape
+        Z = mu.shape[1]
+        dims = _ffi.Dims(B, D, Z)
+        flags = _ffi.COS_LOSS if cos_loss else 0
+        loss3 = torch.empty(3, dtype=torch.float32, device=x_hat.device)
+        scratch = buffers.scratch(B, D, Z, x_hat.device)
+        _ffi.check(_ffi.lib().psvae_elbo_f32(C.byref(dims), _ffi.ptr(x), _ffi.ptr(x_hat), _ffi.ptr(mu), _ffi.ptr(lv), 1.0,
+                                             _ffi.ptr(loss3), _ffi.ptr(scratch), flags, _ffi.stream_ptr()), "elbo")
+        ctx.save_for_backward(x_hat, mu, lv, x)
+        ctx.flags = flags
+        return loss3[1], loss3[2]
+
+    @staticmethod
+    def backward(ctx, g_recon, g_kl):
+        import ctypes as C
+        x_hat, mu, lv, x = ctx.saved_tensors
+        B, D = x_hat.shape
+        dims = _ffi.Dims(B, D, mu.shape[1])
+        zero = lambda g: torch.zeros((), dtype=torch.float32, device=x_hat.device) if g is None else g.float().contiguous()
+        gr, gk = zero(g_recon), zero(g_kl)
+        g_xh, g_mu, g_lv = torch.empty_like(x_hat), torch.empty_like(mu), torch.empty_like(lv)
+        _ffi.check(_ffi.lib().psvae_elbo_grad_f32(C.byref(dims), _ffi.ptr(x), _ffi.ptr(x_hat), _ffi.ptr(mu), _ffi.ptr(lv),
+                                                  _ffi.ptr(gr), _ffi.ptr(gk), _ffi.ptr(g_xh), _ffi.ptr(g_mu), _ffi.ptr(g_lv),
+                                                  ctx.flags, _ffi.stream_ptr()), "elbo_grad")
+        return g_xh, g_mu, g_lv, None, None, None
+
+
 class DecodeFunction(torch.autograd.Function):
     """x_hat = decoder(z) on the HIP decode path.  The reference only ever detaches the result
     (inference.py:25,105), so the forward is always available; a backward through decode() is not
@@ -418,6 +456,11 @@ class VAEModel(nn.Module):
         total, recon, kl, ce, hits, _, _, xh, mu, lv = self.elbo_heads_step(
             x, y, classifier, None, beta, classifier_weight, 1.0, use_cos_loss, eps)
         return total, recon, kl, ce, hits, xh, mu, lv
+
+    def elbo_terms(self, x_hat: torch.Tensor, mu: torch.Tensor, log_sigma: torch.Tensor, x: torch.Tensor,
+                   use_cos_loss: bool = False):
+        """(recon, kl) of lightning.py:110-117 for given forward outputs, computed and differentiated by the HIP kernels"""
+        return ELBOTermsFunction.apply(x_hat, mu, log_sigma, x, bool(use_cos_loss), self._scratch_cache)
 
     def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
                   eps: Optional[torch.Tensor] = None):

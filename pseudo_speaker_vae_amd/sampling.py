@@ -20,11 +20,28 @@ def _latent_dim(vae_model) -> int:
     return vae_model.hparams.model["latent_dim"]
 
 
+# The samplers draw from their OWN Philox stream: key = torch's seed XOR a constant (so the draws never coincide with
+# the epsilon stream of VAEModel._next_rng, which uses the plain seed), and a starting block taken FROM TORCH'S DEFAULT
+# GENERATOR (one 62-bit draw per call).  So, as with the reference's torch.randn (inference.py:23,73,95): every call
+# advances torch's generator and returns fresh samples, and torch.manual_seed() makes the sequence of calls repeatable.
+_SAMPLER_KEY_XOR = 0x5A17D00DC0FFEE11
+
+
+def _take_blocks(nblk: int, seed: Optional[int] = None):
+    """(key, first block) of this call's draw.  An explicit `seed` gives a private, repeatable stream that starts at
+    block 0 and leaves torch's generator alone."""
+    if seed is not None:
+        return (int(seed) ^ _SAMPLER_KEY_XOR) & ((1 << 64) - 1), 0
+    key = (torch.initial_seed() ^ _SAMPLER_KEY_XOR) & ((1 << 64) - 1)
+    first = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())  # 2^62 blocks apart w.h.p.: no overlap
+    return key, first
+
+
 def unconditional_synthesis(vae_model, num_samples: int, device: str, seed: Optional[int] = None) -> torch.Tensor:
     """inference.py:10-27."""
     dim = _latent_dim(vae_model)
-    seed = torch.initial_seed() if seed is None else seed
-    z = ops.philox_normal(num_samples * dim, seed & ((1 << 64) - 1), 0, device).view(num_samples, dim)
+    key, off = _take_blocks((num_samples * dim + 3) // 4, seed)
+    z = ops.philox_normal(num_samples * dim, key, off, device).view(num_samples, dim)
     with torch.no_grad():
         return vae_model.decode(z).detach().cpu()
 
@@ -81,12 +98,13 @@ def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[
     dim = _latent_dim(vae_model)
     fus = _fusable_classifier(getattr(vae_model, "classifier", None), classifier_target)
     if fus is not None and torch.device(device).type == "cuda":
-        # fused HIP path: z0 and the noise from the device Philox stream (seeded by torch.manual_seed)
-        seed = torch.initial_seed() & ((1 << 64) - 1)
+        # fused HIP path: z0 and the per-step noise from the samplers' device Philox stream (follows torch.manual_seed;
+        # every call consumes (1 + num_steps) * nblk fresh blocks)
         nblk = (num_samples * dim + 3) // 4
-        z_init = ops.philox_normal(num_samples * dim, seed, 0, device).view(num_samples, dim) if z0 is None else z0.to(device)
+        key, off = _take_blocks((1 + num_steps) * nblk)
+        z_init = ops.philox_normal(num_samples * dim, key, off, device).view(num_samples, dim) if z0 is None else z0.to(device)
         z, hist = langevin_fused(fus, z_init, classifier_target, step_size, noise_weight, num_steps, noises,
-                                 seed=seed, offset=nblk, return_history=return_history)
+                                 seed=key, offset=off + nblk, return_history=return_history)
         with torch.no_grad():
             x_hat = vae_model.decode(z).detach().cpu()
         if return_history:

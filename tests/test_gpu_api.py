@@ -167,9 +167,11 @@ def test_fused_langevin_equals_torch_loop_and_is_deterministic():
     assert_close(hist.cpu(), torch.stack(href), REL_TOL, "history")
     torch.manual_seed(9)
     a = sampling.conditional_synthesis(mod, 50, 2, 0.05, 20, 1.0, device=DEV)
+    a2 = sampling.conditional_synthesis(mod, 50, 2, 0.05, 20, 1.0, device=DEV)   # no reseed: a fresh chain
     torch.manual_seed(9)
     b = sampling.conditional_synthesis(mod, 50, 2, 0.05, 20, 1.0, device=DEV)
     assert a.shape == (50, 256) and torch.equal(a, b) and torch.isfinite(a).all()
+    assert not torch.equal(a, a2)
     # classifier guidance does something: mean log p(target) after sampling beats the prior draw
     z_prior = torch.randn(2000, 64, device=DEV)
     zg, _ = sampling.langevin_fused(fus, z_prior, 2, 0.2, 0.1, 200)
@@ -183,12 +185,26 @@ def test_unconditional_synthesis_shapes_and_determinism():
     from ps_vae.lightning import PseudoSpeakerVAE
     torch.manual_seed(0)
     mod = PseudoSpeakerVAE(model=dict(input_dim=256, latent_dim=64)).to(DEV)
+    from pseudo_speaker_vae_amd import sampling
     a = unconditional_synthesis(mod, 16, DEV, seed=5)
     b = unconditional_synthesis(mod, 16, DEV, seed=5)
     assert a.shape == (16, 256) and a.device.type == "cpu" and torch.equal(a, b)
     p = O.init_params(256, 64, 0)
-    z = torch.from_numpy(O.philox_normal(16 * 64, 5, 0).reshape(16, 64))
+    key = (5 ^ sampling._SAMPLER_KEY_XOR) & ((1 << 64) - 1)  # the samplers' own stream, apart from the model's epsilon
+    z = torch.from_numpy(O.philox_normal(16 * 64, key, 0).reshape(16, 64))
     assert_close(a, O.decode(p, z), REL_TOL, "decode of the Philox draw")
+    # ADVICE (round 1): the reference's torch.randn gives FRESH draws on every call (inference.py:23); so here --
+    # consecutive calls differ, torch.manual_seed starts the stream over, and the draw is not the model's epsilon
+    torch.manual_seed(77)
+    c1 = unconditional_synthesis(mod, 16, DEV)
+    c2 = unconditional_synthesis(mod, 16, DEV)
+    assert not torch.equal(c1, c2)
+    torch.manual_seed(77)
+    d1 = unconditional_synthesis(mod, 16, DEV)
+    d2 = unconditional_synthesis(mod, 16, DEV)
+    assert torch.equal(c1, d1) and torch.equal(c2, d2)
+    z_model_stream = torch.from_numpy(O.philox_normal(16 * 64, 77, 0).reshape(16, 64))  # what VAEModel's first eps is
+    assert not torch.allclose(d1, O.decode(p, z_model_stream), atol=1e-3)
 
 
 def test_engine_graph_equals_eager_and_matches_oracle():

@@ -280,3 +280,49 @@ def test_label_out_of_range_is_reported_by_the_fused_heads():
     y[7] = 3
     with pytest.raises(_ffi.PsvaeError, match="label"):
         clf.cross_entropy_step(z, y)
+
+
+@pytest.mark.parametrize("cos", [False, True])
+def test_elbo_terms_on_hip_match_the_reference_formulas_and_autograd(cos):
+    """the general training_step branch (multi-label heads, frozen VAE; lightning.py:110-117) takes recon and kl -- and
+    their gradients -- from psvae_elbo_f32 / psvae_elbo_grad_f32: same values and derivatives as the reference's
+    F.mse_loss / F.cosine_embedding_loss / KL expression under torch autograd (CPU, fp32)"""
+    import torch.nn.functional as F
+    from pseudo_speaker_vae_amd.model import VAEModel
+    B, D, Z = 200, 256, 64
+    torch.manual_seed(5)
+    m = VAEModel(D, Z).to(DEV)
+    x = torch.randn(B, D)
+    xh, mu, lv = (torch.randn(B, D) * 0.7, torch.randn(B, Z) * 0.5, torch.randn(B, Z) * 0.3)
+    leaves = [t.clone().to(DEV).requires_grad_() for t in (xh, mu, lv)]
+    recon, kl = m.elbo_terms(*leaves, x.to(DEV), cos)
+    (1.7 * recon - 0.4 * kl).backward()
+    ref = [t.clone().requires_grad_() for t in (xh, mu, lv)]
+    r_ref = F.cosine_embedding_loss(ref[0], x, torch.ones(B)) if cos else F.mse_loss(ref[0], x, reduction="mean") / 10
+    k_ref = -0.5 * torch.mean(torch.sum(1 + ref[2] - ref[1].pow(2) - ref[2].exp(), dim=-1))
+    (1.7 * r_ref - 0.4 * k_ref).backward()
+    assert abs(float(recon) - float(r_ref)) <= REL_TOL * max(1.0, abs(float(r_ref)))
+    assert abs(float(kl) - float(k_ref)) <= REL_TOL * max(1.0, abs(float(k_ref)))
+    for name, a, b in zip(("g_xhat", "g_mu", "g_logvar"), leaves, ref):
+        assert_close(a.grad, b.grad, REL_TOL, name)
+
+
+def test_training_step_general_branch_uses_hip_elbo():
+    """multi-label classifier heads take the general branch of training_step: its ELBO terms come from the HIP kernels,
+    and the whole thing still backpropagates into every parameter"""
+    from ps_vae.lightning import PseudoSpeakerVAE
+    D, Z, B = 128, 32, 40
+    torch.manual_seed(0)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z),
+                           classifier=dict(input_dim=Z, num_classes={"a": 3, "b": 2}, num_layers=2, hidden_dim=32,
+                                           activation="relu"), classifier_loss_weight=0.5).to(DEV)
+    x = torch.randn(B, D, device=DEV)
+    y = {"a": torch.randint(0, 3, (B,), device=DEV), "b": torch.randint(0, 2, (B,), device=DEV)}
+    out = mod.training_step((x, y), 0)
+    assert type(out["loss"].grad_fn).__name__ != "NoneType"
+    out["loss"].backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in mod.parameters())
+    r, k = float(mod.logged["train_recon_loss"]), float(mod.logged["train_kl_loss"])
+    # (lightning.py:90-95: the per-head log carries the running sum; the mean over the two heads enters the total)
+    cum = float(mod.logged["train_classifier_loss_b"])
+    assert r > 0 and k > 0 and abs(float(out["loss"]) - (r + k + 0.5 * cum / 2)) < 1e-4

@@ -139,3 +139,39 @@ def test_data_parallel_epsilon_stream_is_world_size_invariant(graph):
         assert torch.equal(eps_sh, eps_full), f"step {step}"
         seen.append(eps_full)
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])  # fresh noise every step
+
+
+def test_langevin_rows_are_independent_at_one_million_rows():
+    """cfg5, conditional leg (inference.py:72-105) at BASELINE size: 1,000,000 latent rows x 100 Langevin steps in one
+    launch.  Every row's chain depends on its own z0 and its own noise blocks only: any slice run alone -- with the
+    Philox offsets of its rows -- reproduces the big run bit for bit across workgroup boundaries; and a slice's whole
+    history matches the oracle's loop fed the same noise."""
+    from pseudo_speaker_vae_amd import ops, sampling
+    from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
+    N, Z, T, target, step, nw = 1_000_000, 64, 100, 1, 0.05, 0.7
+    torch.manual_seed(0)
+    clf = LatentClassifier(Z, 3, num_layers=2, hidden_dim=128).to(DEV)
+    with torch.no_grad():
+        for q in clf.parameters():
+            q.mul_(2.0)
+    fus = sampling._fusable_classifier(clf, target)
+    z0 = ops.philox_normal(N * Z, 123, 0, DEV).view(N, Z)
+    nblk = N * Z // 4
+    zT, _ = sampling.langevin_fused(fus, z0, target, step, nw, T, seed=321, offset=0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(zT).all()
+    # (a) slices alone, with injected noise = the big run's Philox blocks of those rows
+    for lo, hi in ((0, 64), (255, 321), (499_968, 500_100), (N - 50, N)):
+        n = hi - lo
+        noises = torch.stack([ops.philox_normal(N * Z, 321, t * nblk, DEV).view(N, Z)[lo:hi] for t in range(3)])
+        part3, _ = sampling.langevin_fused(fus, z0[lo:hi].contiguous(), target, step, nw, 3, noises)
+        big3, _ = sampling.langevin_fused(fus, z0, target, step, nw, 3, seed=321, offset=0)
+        assert torch.equal(part3, big3[lo:hi]), f"rows {lo}:{hi} depend on their neighbours"
+    # (b) history parity with the oracle on a slice of the full 100-step run
+    lo, hi = 777_700, 777_732
+    noises = torch.stack([ops.philox_normal(N * Z, 321, t * nblk, DEV).view(N, Z)[lo:hi] for t in range(T)])
+    zs, hist = sampling.langevin_fused(fus, z0[lo:hi].contiguous(), target, step, nw, T, noises, return_history=True)
+    assert torch.equal(zs, zT[lo:hi])
+    layers = [(fus[0].cpu(), fus[1].cpu()), (fus[2].cpu(), fus[3].cpu())]
+    zr, href = O.langevin(layers, z0[lo:hi].cpu(), noises.cpu(), target, step, nw)
+    assert_close(hist.cpu(), torch.stack(href), 1e-4, "100-step history vs oracle")
