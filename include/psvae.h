@@ -189,9 +189,9 @@ int psvae_set_plan(const psvae_dims* dims, const char* text);
 
 /* bf16 variant of psvae_train_step_f32 (BASELINE config 3: bf16 MFMA operands, fp32 accumulate, fp32 master
  * weights, gradients and loss).  D and Z must be multiples of 32.  x, params, grads, outputs, eps_out[B,Z] and
- * z_out[B,Z] are fp32; all bf16 intermediates live in `scratch` (psvae_bf16_scratch_bytes), which the caller
- * must ZERO-FILL once (the batch padding of the transposed copies is read, never written).  cond (nullable)
- * adds the one-hot gather tables. */
+ * z_out[B,Z] are fp32; all bf16 intermediates live in `scratch` (psvae_bf16_scratch_bytes).  Activations and
+ * gradients exist in ONE bf16 layout: the weight gradients read their batch-major operands transposed out of LDS
+ * (ds_read_b64_tr_b16).  cond (nullable) adds the one-hot gather tables. */
 size_t psvae_bf16_scratch_bytes(const psvae_dims* dims);
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params,
                           const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,

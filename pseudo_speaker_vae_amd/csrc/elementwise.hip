@@ -10,23 +10,18 @@
 
 namespace psvae {
 
-// bf16 copies for the bf16 training pass: the elementwise kernels below can emit their result in both bf16 layouts
-// ([rows][cols] and [cols][rows padded to Bp]) so that no separate cast/transpose launch is needed
+// bf16 copies for the bf16 training pass: the elementwise kernels below can emit their result as a row-major bf16 copy
+// too, so that no separate cast launch is needed
 __device__ __forceinline__ unsigned short f2bf_ew(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);
     return *reinterpret_cast<unsigned short*>(&h);
 }
 struct Bf16Out {
     unsigned short* rm[2];   // row-major [B, Z] outputs (nullable)
-    unsigned short* tr[2];   // transposed [Z, Bp] outputs (nullable)
-    int Z, Bp;
 };
 __device__ __forceinline__ void emit_bf16(const Bf16Out& o, int which, int64_t i, float v) {
     if (o.rm[which] == nullptr) return;
-    const unsigned short b = f2bf_ew(v);
-    const int64_t row = i / o.Z, col = i - row * o.Z;
-    o.rm[which][i] = b;
-    o.tr[which][col * (int64_t)o.Bp + row] = b;
+    o.rm[which][i] = f2bf_ew(v);
 }
 
 __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
@@ -397,11 +392,11 @@ __global__ __launch_bounds__(256) void reparam_bwd_final_kernel(
 
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng, uint64_t seed,
                              uint64_t offset, float* eps_out, float* z, float* kl_partials, int64_t n, hipStream_t s,
-                             unsigned short* zb, unsigned short* zbT, int Z, int Bp) {
+                             unsigned short* zb) {
     const int vec_ok = al16(mu) && al16(lv) && al16(eps_out) && al16(z) && (!eps_in || al16(eps_in));
     if (eps_in) rng = nullptr;
     Bf16Out bo{};
-    bo.rm[0] = zb; bo.tr[0] = zbT; bo.Z = Z > 0 ? Z : 1; bo.Bp = Bp;
+    bo.rm[0] = zb;
     hipLaunchKernelGGL(reparam_kl_kernel, dim3(reparam_blocks(n)), dim3(256), 0, s, mu, lv, eps_in, rng, seed, offset,
                        eps_out, z, kl_partials, n, vec_ok, bo);
     return hipGetLastError();
@@ -410,12 +405,10 @@ hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_
 hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const float* lv, const float* eps, float beta,
                                     const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
                                     const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
-                                    float* loss3, uint64_t* rng, hipStream_t s, unsigned short* const* bf_rm,
-                                    unsigned short* const* bf_tr, int Bp) {
+                                    float* loss3, uint64_t* rng, hipStream_t s, unsigned short* const* bf_rm) {
     const int64_t n = (int64_t)B * Z;
     Bf16Out bo{};
-    if (bf_rm) { bo.rm[0] = bf_rm[0]; bo.rm[1] = bf_rm[1]; bo.tr[0] = bf_tr[0]; bo.tr[1] = bf_tr[1]; }
-    bo.Z = Z; bo.Bp = Bp;
+    if (bf_rm) { bo.rm[0] = bf_rm[0]; bo.rm[1] = bf_rm[1]; }
     hipLaunchKernelGGL(reparam_bwd_final_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g_z, mu, lv, eps, beta, go,
                        g_mu, g_lv, n, B, D, kl_partials, n_kl, recon_partials, n_recon, loss3, rng,
                        (uint64_t)((n + 3) / 4), bo);

@@ -1,16 +1,22 @@
 // bf16 MFMA path (BASELINE config 3: bf16 operands, fp32 accumulate, fp32 master weights).
 //
-// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane for BOTH operands, i.e. both operands
-// k-contiguous in memory.  So the bf16 path keeps every activation / gradient / weight tensor in TWO bf16
-// layouts, [rows][features] and [features][rows(padded to 32)], written by the producing kernel's epilogue,
-// and every GEMM is the same "NT" product C[m][n] = sum_k A[m][k] * B[n][k]:
-//   forward  h' = h W^T        A = h  [B,K]        B = W   [N,K]
-//   dgrad    dX = dY W         A = dY [B,N]        B = W^T [K,N]
-//   wgrad    dW = dY^T X       A = dY^T [N,Bpad]   B = X^T [K,Bpad]      (contraction over the padded batch)
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane for BOTH operands.  Activations and gradients exist in ONE
+// bf16 layout, [rows][features]; weights in two ([out,in] and [in,out]: 2.5 MB, cast once per pass).  Every GEMM is
+// C[m][n] = sum_k A[m][k] * B[n][k]:
+//   forward  h' = h W^T        A = h  [B,K]        B = W   [N,K]          (both k-contiguous in memory)
+//   dgrad    dX = dY W         A = dY [B,N]        B = W^T [K,N]          (both k-contiguous)
+//   wgrad    dW = dY^T X       A = dY [B,out]      B = X [B,in]           (both k-MAJOR: the batch is the row index)
+// The weight gradients therefore stage their [64 batch rows][128 features] operand tiles in LDS exactly as they lie in
+// memory (whole 256-B row segments, coalesced) and read the fragments TRANSPOSED with ds_read_b64_tr_b16 (a 4 x 16
+// block per 16 lanes, delivered column-major: cdna_hip_programming.md T10) -- no second copy of any activation is ever
+// written (round 1 kept a [features][batch] copy of each: 48 MB of extra stores per step at B = 4096).
 // Structure as the fp32 kernel (csrc/gemm_f32.hip): register-direct fragments (one 16-B load = 8 bf16 per
 // lane per 16-row block per 32-k chunk, no permutation needed), D chunks in flight, split-K across the 4
 // waves, one LDS meeting point for the k slices, fused epilogue writing fp32 and/or both bf16 layouts.
 #include <hip/hip_bf16.h>
+
+#include <mutex>
+#include <type_traits>
 
 #include "psvae_common.h"
 
@@ -58,6 +64,14 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     const u16* __restrict__ A = d.A;
     const u16* __restrict__ B = d.B;
 
+#ifdef PSVAE_STAMP
+    unsigned long long st_[16];
+    int nst_ = 0;
+#define STAMP() do { if (nst_ < 16) st_[nst_++] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP();
+#else
+#define STAMP() do {} while (0)
+#endif
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -69,7 +83,104 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     const bool do_colsum = (d.colsum != nullptr) && (tn == 0) && (wn == 0);
 
     if constexpr (STAGED) {
-        static_assert(KS == 1 && WM == 2 && WN == 2 && TM == 4 && TN == 4, "staged loop: 128x128 tile, 2x2 waves");
+      static_assert(KS == 1 && WM == 2 && WN == 2 && TM == 4 && TN == 4, "staged loop: 128x128 tile, 2x2 waves");
+      typedef std::integral_constant<int, 0> I0;
+      typedef std::integral_constant<int, 1> I1;
+      if (d.tr) {
+        // ---- k-MAJOR operands (weight gradients): A = dY [K rows = batch][M], B = X [K][N], row-major as produced.
+        // LDS image [64 k][128 + 8] per operand and buffer; fragments come out transposed (see the file header).
+        constexpr int BK = 64, LSM = BM + 8;               // 272-B rows: every piece and every tr address 8-B aligned
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        u16* sA = reinterpret_cast<u16*>(smem);            // [2][BK][LSM]
+        u16* sB = sA + 2 * BK * LSM;                       // [2][BK][LSM]
+        const int krow = tid >> 4, mcol = (tid & 15) * 8;  // piece (k row, feature) of pass i: k = krow + 16 i
+        // a piece is fetched when it lies inside the row pitch (pitches are multiples of 8; columns between the valid
+        // extent and the pitch are zero by construction: the one-hot label matrix); batch rows >= K read as zeros
+        const bool okA = m0 + mcol + 8 <= d.lda, okB = n0 + mcol + 8 <= d.ldb;
+        const u16* ga = A + (size_t)krow * d.lda + (okA ? m0 + mcol : 0);
+        const u16* gb = B + (size_t)krow * d.ldb + (okB ? n0 + mcol : 0);
+        // TWO k tiles in flight in registers (sets 0 / 1) on top of the two LDS buffers: with one the loop exposed a
+        // full memory round trip per 64-row tile (the bf16 MFMAs of a tile take 0.2 us, the fetch ~2 us)
+        bf16x8 ra_[2][4], rb_[2][4];
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto gload = [&](auto P, int t) {
+            constexpr int p = decltype(P)::value;
+            const int k0 = t * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = k0 + krow + 16 * i < K;
+                ra_[p][i] = (in && okA) ? ldgb<bf16x8>(ga + (size_t)(k0 + 16 * i) * d.lda) : zero8;
+                rb_[p][i] = (in && okB) ? ldgb<bf16x8>(gb + (size_t)(k0 + 16 * i) * d.ldb) : zero8;
+            }
+        };
+        auto lstore = [&](auto P, int buf) {
+            constexpr int p = decltype(P)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<bf16x8*>(sA + (buf * BK + krow + 16 * i) * LSM + mcol) = ra_[p][i];
+                *reinterpret_cast<bf16x8*>(sB + (buf * BK + krow + 16 * i) * LSM + mcol) = rb_[p][i];
+            }
+        };
+        const int nt_all = (K + BK - 1) / BK;
+        const int S = d.ksplit > 1 ? d.ksplit : 1;
+        const int per = (nt_all + S - 1) / S;
+        const int t_beg = ksg * per;
+        const int nt = (t_beg + per < nt_all ? t_beg + per : nt_all);  // end (exclusive)
+        if (t_beg < nt) gload(I0{}, t_beg);
+        if (t_beg + 1 < nt) gload(I1{}, t_beg + 1);
+        if (t_beg < nt) lstore(I0{}, 0);  // (waits for the first tile's loads only: vmcnt counts in issue order)
+        __syncthreads();
+        STAMP();
+        // lane (r, q) of the MFMA wants k = 32 s2 + 8 q + 0..7 of feature column r of its block: two transposed reads
+        // of 4 k rows each; inside its 16-lane group the lane SUPPLIES the address of (k row r >> 2, features 4 (r & 3)..)
+        const int tr_off = (8 * q + (r >> 2)) * LSM + 4 * (r & 3);
+        auto trd = [&](const u16* p) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4s*)(reinterpret_cast<uintptr_t>(p)));
+        };
+        // iteration of tile t (parity p = (t - t_beg) & 1): LDS buffer p holds it, register set 1-p holds tile t+1 (in
+        // flight since the previous iteration), register set p is free: tile t+2 is requested into it
+        auto iter = [&](auto P, int t) {
+            constexpr int p = decltype(P)::value;
+            typedef std::integral_constant<int, 1 - p> Q;
+            const int buf = p;
+            if (t + 2 < nt) gload(P, t + 2);
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 32; ++s2) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const u16* pa = sA + (buf * BK + 32 * s2) * LSM + tr_off + wm * 64 + 16 * m;
+                    const v4s lo = trd(pa), hi = trd(pa + 4 * LSM);
+                    fa[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const u16* pb = sB + (buf * BK + 32 * s2) * LSM + tr_off + wn * 64 + 16 * n;
+                    const v4s lo = trd(pb), hi = trd(pb + 4 * LSM);
+                    fb[n] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                if (do_colsum) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) csum[m] += bf2f((u16)fa[m][e]);
+                }
+            }
+            if (t + 1 < nt) lstore(Q{}, buf ^ 1);
+            __syncthreads();
+            STAMP();
+        };
+        for (int t = t_beg; t < nt; t += 2) {
+            iter(I0{}, t);
+            if (t + 1 < nt) iter(I1{}, t + 1);
+        }
+      } else {
         constexpr int BK = 64, LS = BK + 8;  // LDS row stride in bf16: 144 B keeps ds_read_b128 of 16 rows conflict-free
         u16* sA = reinterpret_cast<u16*>(smem);            // [2][BM][LS]
         u16* sB = sA + 2 * BM * LS;                        // [2][BN][LS]
@@ -85,22 +196,24 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             ga[i] = A + (size_t)ra * d.lda + pk;
             gb[i] = B + (size_t)rb * d.ldb + pk;
         }
-        bf16x8 ra_[4], rb_[4];
+        bf16x8 ra_[2][4], rb_[2][4];  // two k tiles in flight in registers (see the k-major loop above)
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto gload = [&](int t) {
+        auto gload = [&](auto P, int t) {
+            constexpr int p = decltype(P)::value;
             const int k0 = t * BK;
             const bool in = k0 + pk < K;  // K % 32 == 0: the last tile may hold only its first half
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra_[i] = in ? ldgb<bf16x8>(ga[i] + k0) : zero8;
-                rb_[i] = in ? ldgb<bf16x8>(gb[i] + k0) : zero8;
+                ra_[p][i] = in ? ldgb<bf16x8>(ga[i] + k0) : zero8;
+                rb_[p][i] = in ? ldgb<bf16x8>(gb[i] + k0) : zero8;
             }
         };
-        auto lstore = [&](int buf) {
+        auto lstore = [&](auto P, int buf) {
+            constexpr int p = decltype(P)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<bf16x8*>(sA + (buf * BM + prow + 32 * i) * LS + pk) = ra_[i];
-                *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[i];
+                *reinterpret_cast<bf16x8*>(sA + (buf * BM + prow + 32 * i) * LS + pk) = ra_[p][i];
+                *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[p][i];
             }
         };
         // k tiles of this workgroup: all of them, or slice ksg of a cross-workgroup split (weight gradients)
@@ -109,14 +222,16 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         const int per = (nt_all + S - 1) / S;
         const int t_beg = ksg * per;
         const int nt = (t_beg + per < nt_all ? t_beg + per : nt_all);  // end (exclusive)
-        if (t_beg < nt) {
-            gload(t_beg);
-            lstore(t_beg & 1);
-        }
+        if (t_beg < nt) gload(I0{}, t_beg);
+        if (t_beg + 1 < nt) gload(I1{}, t_beg + 1);
+        if (t_beg < nt) lstore(I0{}, 0);
         __syncthreads();
-        for (int t = t_beg; t < nt; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < nt) gload(t + 1);  // in flight under this tile's MFMAs
+        STAMP();
+        auto iter = [&](auto P, int t) {
+            constexpr int p = decltype(P)::value;
+            typedef std::integral_constant<int, 1 - p> Q;
+            const int buf = p;
+            if (t + 2 < nt) gload(P, t + 2);  // two tiles ahead: in flight under this and the next tile's MFMAs
 #pragma unroll
             for (int s2 = 0; s2 < BK / 32; ++s2) {
                 bf16x8 fa[TM], fb[TN];
@@ -138,9 +253,15 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                         for (int e = 0; e < 8; ++e) csum[m] += bf2f((u16)fa[m][e]);
                 }
             }
-            if (t + 1 < nt) lstore(buf ^ 1);  // the other buffer: last read before the previous barrier
+            if (t + 1 < nt) lstore(Q{}, buf ^ 1);  // the other buffer: last read before the previous barrier
             __syncthreads();
+            STAMP();
+        };
+        for (int t = t_beg; t < nt; t += 2) {
+            iter(I0{}, t);
+            if (t + 1 < nt) iter(I1{}, t + 1);
         }
+      }
         // (the loop's last barrier also fences the staging buffers against the epilogue's reuse of this LDS)
     } else {
     // row pointers (rows clamped: they only feed outputs the epilogue never stores)
@@ -263,137 +384,145 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         }
     }
     __syncthreads();
+    STAMP();
+    // Row loop: EIGHT columns per thread, so that the bf16 output leaves as one 16-byte store per thread and row (whole
+    // 128-B lines per 8 lanes) and the fp32 outputs as two; there is no second (transposed) bf16 copy any more.
     const int epi = d.epi;
-    constexpr int CQ = BN / 4;
+    constexpr int CQ = BN / 8;
     constexpr int RSTEP = NT / CQ;
-    const int c4 = tid % CQ, r0 = tid / CQ;
-    const int col = n0 + 4 * c4;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    const int c8 = tid % CQ, r0 = tid / CQ;
+    const int col = n0 + 8 * c8;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4[2] = {zero4, zero4};
     if (d.bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < N) bias4[e] = ldgb<float>(d.bias + col + e);
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + 4 * h + e < N) bias4[h][e] = ldgb<float>(d.bias + col + 4 * h + e);
     }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ct[6] = {zero4, zero4, zero4, zero4, zero4, zero4};  // this thread's 4 columns of the conditional table
+    f32x4 ct[2][6];  // (!CT instantiations only) this thread's 8 columns of the conditional table
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ct[h][c] = zero4;
     if constexpr (!CT) {
         if (d.ctab) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < N) ct[c][e] = ldgb<float>(d.ctab + (size_t)c * N + col + e);
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + 4 * h + e < N) ct[h][c][e] = ldgb<float>(d.ctab + (size_t)c * N + col + 4 * h + e);
         }
     }
     float sq = 0.f;
     const float gsc = (epi == BEPI_RECON) ? d.scale * (d.go ? ldgb<float>(d.go) : 1.0f) : 0.f;
-    const bool colfull = col + 3 < N;
-#pragma unroll
+    const bool colfull = col + 7 < N;
+    // not unrolled: measured 211 / 213 / 213 / 218 us per cfg3 step at unroll 1 / 2 / 4 / 8 -- the loop is bound by the
+    // store burst of all workgroups at once (in-kernel stamps: 9-17 k cycles of a 29-36 k cycle workgroup), not by latency
+#pragma unroll 1
     for (int rr = 0; rr < BM; rr += RSTEP) {
         const int lr = rr + r0;
         const int row = m0 + lr;
-        if (lr >= BM) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * SC + 4 * c4);
+        if (lr >= BM || row >= M || col >= N) continue;
+        f32x4 v[2];
 #pragma unroll
-        for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 4 * c4);
-        if (row < M && col < N) {
-            v += bias4;
-            if (d.ctab) {  // one-hot conditioning: + table[gender] + table[3 + age], table columns preloaded above
-                const int g = d.gender[row], a = d.age[row];
-                if constexpr (CT) {
-                    const int gi = (unsigned)g < 3u ? g : 6, ai = (unsigned)a < 3u ? 3 + a : 6;
-                    v += *reinterpret_cast<const f32x4*>(ct_s + gi * BN + 4 * c4);
-                    v += *reinterpret_cast<const f32x4*>(ct_s + ai * BN + 4 * c4);
-                } else {
-                    v += (g == 0 ? ct[0] : g == 1 ? ct[1] : g == 2 ? ct[2] : zero4);
-                    v += (a == 0 ? ct[3] : a == 1 ? ct[4] : a == 2 ? ct[5] : zero4);
-                }
-            }
-            if (epi == BEPI_RELU) {
+        for (int h = 0; h < 2; ++h) {
+            v[h] = *reinterpret_cast<const f32x4*>(smem + lr * SC + 8 * c8 + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (epi == BEPI_MASK) {  // ReLU backward: mask = saved bf16 activation [M, ldmask]
-                const u16* mp = d.mask + (size_t)row * d.ldmask + col;
-                if (colfull && ((d.ldmask & 3) == 0)) {
-                    const u32x2 mk = ldgb<u32x2>(mp);  // 4 bf16
-                    const u16 m4[4] = {(u16)(mk.x & 0xffff), (u16)(mk.x >> 16), (u16)(mk.y & 0xffff), (u16)(mk.y >> 16)};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = bf2f(m4[e]) > 0.f ? v[e] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < N) v[e] = bf2f(ldgb<u16>(mp + e)) > 0.f ? v[e] : 0.f;
-                }
-            }
-            if (d.Cf) {  // fp32 output (final outputs, wgrads)
-                float* p = d.Cf + (size_t)ksg * M * d.ldcf + (size_t)row * d.ldcf + col;  // ksplit: this slice's slab
-                if (colfull && ((d.ldcf & 3) == 0)) {
-                    stgb<f32x4>(p, v);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < N) stgb<float>(p + e, v[e]);
-                }
-            }
-            if (epi == BEPI_RECON) {  // v = x_hat: emit the MSE gradient instead of v into the bf16 outputs
-                const float* tp = d.target + (size_t)row * d.ldcf + col;
-                f32x4 xt = zero4;
-                if (colfull && ((d.ldcf & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.target) & 15) == 0)) {
-                    xt = ldgb<f32x4>(tp);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < N) xt[e] = ldgb<float>(tp + e);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float df = (col + e < N) ? v[e] - xt[e] : 0.f;
-                    sq += df * df;
-                    v[e] = gsc * df;
-                }
-            }
-            if (d.Cb) {
-                u16* p = d.Cb + (size_t)row * d.ldcb + col;
-                if (colfull && ((d.ldcb & 3) == 0)) {  // 4 bf16 = one 8-byte store
-                    u32x2 pk;
-                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    stgb<u32x2>(p, pk);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < N) stgb<u16>(p + e, f2bf(v[e]));
-                }
-            }
-        } else {
-            v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k2 = 1; k2 < KS; ++k2) v[h] += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 8 * c8 + 4 * h);
+            v[h] += bias4[h];
         }
-        if (d.CbT) *reinterpret_cast<f32x4*>(smem + lr * SC + 4 * c4) = v;  // final values for the transposed pass
-    }
-    if (d.CbT) {  // transposed bf16 copy [N][ldt]: column reads of the finished tile, 4 rows per lane
-        __syncthreads();
-        constexpr int MQ = BM / 4;            // row quads
-        constexpr int QW = MQ >= 8 ? 8 : MQ;  // quads per 64-item block (BM = 16: 4)
-        constexpr int CW = 64 / QW;           // columns per block (BN is a multiple)
-        constexpr int QB = MQ / QW;
-        static_assert(BN % CW == 0 && MQ % QW == 0, "tile shape vs transposed-store blocks");
-        for (int i = tid; i < BN * MQ; i += NT) {
-            // lane order inside 64 items: QW consecutive row quads (64-B contiguous stores) x CW consecutive columns
-            // (LDS banks 16*mq + n: at most 2-way conflicts, the plain n-major order was 8-way)
-            const int blk = i >> 6, l = i & 63;
-            const int mq = (blk % QB) * QW + (l % QW), n = (blk / QB) * CW + (l / QW);
-            const int gn = n0 + n, gm = m0 + 4 * mq;
-            if (gn >= N) continue;
-            u16* p = d.CbT + (size_t)gn * d.ldt + gm;
-            if (gm + 3 < M && ((d.ldt & 3) == 0)) {
-                u32x2 pk;
-                pk.x = (unsigned)f2bf(smem[(4 * mq + 0) * SC + n]) | ((unsigned)f2bf(smem[(4 * mq + 1) * SC + n]) << 16);
-                pk.y = (unsigned)f2bf(smem[(4 * mq + 2) * SC + n]) | ((unsigned)f2bf(smem[(4 * mq + 3) * SC + n]) << 16);
-                stgb<u32x2>(p, pk);
+        if (d.ctab) {  // one-hot conditioning: + table[gender] + table[3 + age]
+            const int g = d.gender[row], a = d.age[row];
+            if constexpr (CT) {
+                const int gi = (unsigned)g < 3u ? g : 6, ai = (unsigned)a < 3u ? 3 + a : 6;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[h] += *reinterpret_cast<const f32x4*>(ct_s + gi * BN + 8 * c8 + 4 * h);
+                    v[h] += *reinterpret_cast<const f32x4*>(ct_s + ai * BN + 8 * c8 + 4 * h);
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (gm + e < M) stgb<u16>(p + e, f2bf(smem[(4 * mq + e) * SC + n]));
+                for (int h = 0; h < 2; ++h) {
+                    v[h] += (g == 0 ? ct[h][0] : g == 1 ? ct[h][1] : g == 2 ? ct[h][2] : zero4);
+                    v[h] += (a == 0 ? ct[h][3] : a == 1 ? ct[h][4] : a == 2 ? ct[h][5] : zero4);
+                }
+            }
+        }
+        if (epi == BEPI_RELU) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], 0.f);
+        } else if (epi == BEPI_MASK) {  // ReLU backward: mask = saved bf16 activation [M, ldmask]
+            const u16* mp = d.mask + (size_t)row * d.ldmask + col;
+            if (colfull && ((d.ldmask & 7) == 0)) {
+                const bf16x8 mk = ldgb<bf16x8>(mp);  // 8 bf16 = 16 B
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[h][e] = bf2f((u16)mk[4 * h + e]) > 0.f ? v[h][e] : 0.f;
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + 4 * h + e < N) v[h][e] = bf2f(ldgb<u16>(mp + 4 * h + e)) > 0.f ? v[h][e] : 0.f;
+            }
+        }
+        if (d.Cf) {  // fp32 output (final outputs, wgrads)
+            float* p = d.Cf + (size_t)ksg * M * d.ldcf + (size_t)row * d.ldcf + col;  // ksplit: this slice's slab
+            if (colfull && ((d.ldcf & 3) == 0)) {
+                stgb<f32x4>(p, v[0]);  // (nontemporal stores for the split-K slabs were measured: no difference)
+                stgb<f32x4>(p + 4, v[1]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + 4 * h + e < N) stgb<float>(p + 4 * h + e, v[h][e]);
+            }
+        }
+        if (epi == BEPI_RECON) {  // v = x_hat: emit the MSE gradient instead of v into the bf16 output
+            const float* tp = d.target + (size_t)row * d.ldcf + col;
+            f32x4 xt[2] = {zero4, zero4};
+            if (colfull && ((d.ldcf & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.target) & 15) == 0)) {
+                xt[0] = ldgb<f32x4>(tp);
+                xt[1] = ldgb<f32x4>(tp + 4);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + 4 * h + e < N) xt[h][e] = ldgb<float>(tp + 4 * h + e);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float df = (col + 4 * h + e < N) ? v[h][e] - xt[h][e] : 0.f;
+                    sq += df * df;
+                    v[h][e] = gsc * df;
+                }
+        }
+        if (d.Cb) {
+            u16* p = d.Cb + (size_t)row * d.ldcb + col;
+            if (colfull && ((d.ldcb & 7) == 0)) {  // 8 bf16 = one 16-byte store
+                bf16x8 pk;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[4 * h + e] = (short)f2bf(v[h][e]);
+                stgb<bf16x8>(p, pk);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + 4 * h + e < N) stgb<u16>(p + 4 * h + e, f2bf(v[h][e]));
             }
         }
     }
@@ -406,6 +535,14 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         __syncthreads();
         if (tid == 0) stgb<float>(d.partials + tm * d.tiles_n + tn, (red[0] + red[1]) + (red[2] + red[3]));
     }
+#ifdef PSVAE_STAMP
+    STAMP();
+    if (STAGED && tid == 0 && tm == 0 && tn == 0 && ksg == 0) {
+        printf("stamp tr=%d M=%d N=%d K=%d ks=%d:", d.tr, M, N, K, d.ksplit);
+        for (int i = 1; i < nst_; ++i) printf(" %llu", st_[i] - st_[i - 1]);
+        printf("\n");
+    }
+#endif
     if (d.colsum != nullptr && tn == 0 && tid < BM) {
         float s = csum_s[tid];
 #pragma unroll
@@ -424,6 +561,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatchBf batch)
     const GemmDescBf& d = batch.d[di];
     int lt = tile - d.tile_begin;
     const int tiles_mn = d.tiles_m * d.tiles_n;
+    if (batch.xcd_remap) {
+        // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Give XCD
+        // x the CONTIGUOUS tile range [x T/8, (x+1) T/8) of this problem: tiles that share an operand panel (the column
+        // tiles of one 128-row panel; the 16 tiles of one batch slice of a weight gradient) then share one L2 instead
+        // of every L2 pulling every panel from Infinity Cache -- at B = 4096 these launches are bound by exactly that
+        // traffic.  Bijective for any T (cdna guide T1).
+        const int T = tiles_mn * ((STAGED && d.ksplit > 1) ? d.ksplit : 1), q8 = T >> 3, r8 = T & 7;
+        const int xcd = lt & 7, idx = lt >> 3;
+        lt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
     const int ksg = STAGED ? lt / tiles_mn : 0;  // cross-workgroup k slice (staged kernel only)
     lt -= ksg * tiles_mn;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
@@ -446,13 +593,17 @@ static hipError_t launch_bf_ct(GemmBatchBf& b, hipStream_t stream) {
         t += b.d[i].tiles_m * b.d[i].tiles_n * S;
     }
     b.total_tiles = t;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 96 * 1024 ? lds : 96 * 1024));
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const char* e = getenv("PSVAE_BF16_XCD");  // tuning (read per call: tests flip it in-process)
+        b.xcd_remap = e ? atoi(e) : 1;
     }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 96 * 1024 ? lds : 96 * 1024));
+    });
+    if (attr_err != hipSuccess) return attr_err;
     // more workgroups than CUs: one workgroup per CU at a time (co-resident workgroups thrash the shared L1, see
     // gemm_f32.hip); the request only has to exceed half the CU's LDS
     static const bool cap_on = getenv("PSVAE_BF16_CAP") != nullptr && atoi(getenv("PSVAE_BF16_CAP")) != 0;  // measured: slower here
@@ -506,25 +657,27 @@ struct CastArgs {
     u16* dstT[12];
     int R[12], Cc[12], ld[12], ldt[12], tile_begin[12];
     int n;
-    // optional rider: the transposed one-hot label matrix ohT[6][Bp] (blocks past the cast tiles)
+    // optional rider: the one-hot label matrix oh[B][8] (bf16 0/1; columns 6, 7 zero), blocks past the cast tiles
     int cast_tiles;
     const int32_t* gender;
     const int32_t* age;
-    u16* ohT;
-    int B, Bp;
+    u16* oh;
+    int B;
 };
 
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const CastArgs a) {
     __shared__ float tile[32][33];
-    if ((int)blockIdx.x >= a.cast_tiles) {  // one-hot rider blocks (one launch fewer per step)
+    if ((int)blockIdx.x >= a.cast_tiles) {  // one-hot rider blocks (one launch fewer per step): one 16-B row per thread
         const int b = ((int)blockIdx.x - a.cast_tiles) * 256 + threadIdx.x;
-        if (b < a.Bp) {
-            const int g = b < a.B ? a.gender[b] : -1, ag = b < a.B ? a.age[b] : -1;
+        if (b < a.B) {
+            const int g = a.gender[b], ag = a.age[b];
+            bf16x8 row = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                a.ohT[(size_t)c * a.Bp + b] = (g == c) ? (u16)0x3F80 : (u16)0;
-                a.ohT[(size_t)(3 + c) * a.Bp + b] = (ag == c) ? (u16)0x3F80 : (u16)0;
+                row[c] = (g == c) ? (short)0x3F80 : (short)0;
+                row[3 + c] = (ag == c) ? (short)0x3F80 : (short)0;
             }
+            *reinterpret_cast<bf16x8*>(a.oh + (size_t)b * 8) = row;
         }
         return;
     }
@@ -558,7 +711,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const CastArgs a) {
 
 hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* const* dstT, const int* R, const int* Cc,
                                  const int* ld, const int* ldt, int n, hipStream_t s, const int32_t* gender,
-                                 const int32_t* age, u16* ohT, int B, int Bp) {
+                                 const int32_t* age, u16* oh, int B) {
     CastArgs a{};
     int t = 0;
     for (int i = 0; i < n; ++i) {
@@ -569,29 +722,11 @@ hipError_t launch_cast_transpose(const float* const* src, u16* const* dst, u16* 
     }
     a.n = n;
     a.cast_tiles = t;
-    if (ohT) {
-        a.gender = gender; a.age = age; a.ohT = ohT; a.B = B; a.Bp = Bp;
-        t += (Bp + 255) / 256;
+    if (oh) {
+        a.gender = gender; a.age = age; a.oh = oh; a.B = B;
+        t += (B + 255) / 256;
     }
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(t), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-// one-hot matrix of the labels, transposed: ohT[c][b] (bf16 0/1), c < 6, b < Bp (padding columns zero).
-// With it the conditional-table gradient  gtab[c][n] = sum_b onehot[b][c] dY[b][n]  is one more wgrad GEMM.
-__global__ __launch_bounds__(256) void onehot_t_kernel(const int32_t* __restrict__ gender, const int32_t* __restrict__ age,
-                                                       u16* __restrict__ ohT, int B, int Bp) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= Bp) return;
-    const int g = b < B ? gender[b] : -1, a = b < B ? age[b] : -1;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        ohT[(size_t)c * Bp + b] = (g == c) ? (u16)0x3F80 : (u16)0;
-        ohT[(size_t)(3 + c) * Bp + b] = (a == c) ? (u16)0x3F80 : (u16)0;
-    }
-}
-hipError_t launch_onehot_t(const int32_t* gender, const int32_t* age, u16* ohT, int B, int Bp, hipStream_t s) {
-    hipLaunchKernelGGL(onehot_t_kernel, dim3((Bp + 255) / 256), dim3(256), 0, s, gender, age, ohT, B, Bp);
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // extern "C" entry points of the bf16 path (BASELINE config 3): bf16 MFMA operands, fp32 accumulation,
 // fp32 master weights / gradients / loss.  One call = one training pass; see gemm_bf16.hip for the layout
-// idea (every tensor in two bf16 layouts so that every GEMM has both operands k-contiguous).
+// idea (activations in ONE bf16 layout; the weight gradients read their k-major operands transposed out of LDS).
 #include "psvae_common.h"
 
 using namespace psvae;
@@ -16,28 +16,28 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
         if (_e != hipSuccess) return (int)_e; \
     } while (0)
 
-// Large batches (B >= 2048): every backward launch uses the LDS-staged 128x128 kernel (half the operand bytes per FLOP of
-// the 64x64 tiles: the bf16 GEMMs are pure operand traffic), and the weight gradients, which have only 16 such tiles,
-// cut the batch over S workgroups per tile; the fp32 partial slabs are summed in fixed order by one launch at the end.
+// Every backward launch uses the LDS-staged 128x128 kernel (half the operand bytes per FLOP of the 64x64 tiles: the bf16
+// GEMMs are pure operand traffic; the weight gradients read their batch-major operands transposed out of the staged
+// tiles).  The weight gradients have only 16 such tiles each, so they cut the batch over S workgroups per tile (512
+// batch rows per slice, at least 256); the fp32 partial slabs are summed in fixed order by one launch at the end.
 constexpr int BF_SMAX = 8;
-inline int bf_wgrad_split(int Bp) {
-    const char* e = getenv("PSVAE_BF16_WGRAD_S");  // tuning / tests (0 = the 64x64 k-split-4 path for every batch size)
-    if (e) { const int v = atoi(e); return v < 0 ? 0 : (v > BF_SMAX ? BF_SMAX : v); }
-    if (Bp < 2048) return 0;
-    const int s = Bp / 512;
-    return s > BF_SMAX ? BF_SMAX : s;
+inline int bf_wgrad_split(int B) {
+    const char* e = getenv("PSVAE_BF16_WGRAD_S");  // tuning / tests
+    if (e) { const int v = atoi(e); return v < 1 ? 1 : (v > BF_SMAX ? BF_SMAX : v); }
+    const int s = B >= 2048 ? B / 512 : (B + 255) / 256;
+    return s < 1 ? 1 : (s > BF_SMAX ? BF_SMAX : s);
 }
 
 struct BfScratch {
     // weights: row-major bf16 copies Wb[i] ([out,in]) and transposed WbT[i] ([in,out]) of the 9 matrices
     u16 *Wb[9], *WbT[9];
-    u16 *xb, *xbT;                                  // [B,D], [D,Bp]
-    u16 *h1m, *h1mT, *h2m, *h2mT, *h1s, *h1sT, *h2s, *h2sT, *d1, *d1T, *d2, *d2T;  // [B,H] / [H,Bp]
-    u16 *zb, *zbT;                                  // [B,Z], [Z,Bp]
-    u16 *gy, *gyT;                                  // [B,D], [D,Bp]
-    u16 *dd2, *dd2T, *dd1, *dd1T, *dh2m, *dh2mT, *dh2s, *dh2sT, *dh1m, *dh1mT, *dh1s, *dh1sT;  // [B,H] / [H,Bp]
-    u16 *gmu, *gmuT, *glv, *glvT;                   // [B,Z] / [Z,Bp]
-    u16* ohT;                                       // [6,Bp] one-hot labels, transposed
+    u16 *xb;                                        // [B,D]
+    u16 *h1m, *h2m, *h1s, *h2s, *d1, *d2;           // [B,H] activations, ONE layout each
+    u16 *zb;                                        // [B,Z]
+    u16 *gy;                                        // [B,D]
+    u16 *dd2, *dd1, *dh2m, *dh2s, *dh1m, *dh1s;     // [B,H]
+    u16 *gmu, *glv;                                 // [B,Z]
+    u16* oh;                                        // [B,8] one-hot labels (columns 6, 7 zero)
     float *gz, *gmu_f, *glv_f, *kl_partials, *recon_partials;
     // large batches: weight-gradient partials of the cross-workgroup split (BF_SMAX slices each), summed at the end
     float *slab_w[9], *slab_b[9], *slab_t[3];
@@ -69,14 +69,14 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
         s.Wb[k] = tb((size_t)wo[k] * wi[k]);
         s.WbT[k] = tb((size_t)wi[k] * wo[k]);
     }
-    s.xb = tb(B * D); s.xbT = tb(D * Bp);
+    (void)Bp;
+    s.xb = tb(B * D);
     u16** hs[] = {&s.h1m, &s.h2m, &s.h1s, &s.h2s, &s.d1, &s.d2, &s.dd2, &s.dd1, &s.dh2m, &s.dh2s, &s.dh1m, &s.dh1s};
-    u16** hts[] = {&s.h1mT, &s.h2mT, &s.h1sT, &s.h2sT, &s.d1T, &s.d2T, &s.dd2T, &s.dd1T, &s.dh2mT, &s.dh2sT, &s.dh1mT, &s.dh1sT};
-    for (int k = 0; k < 12; ++k) { *hs[k] = tb(B * H); *hts[k] = tb((size_t)H * Bp); }
-    s.zb = tb(B * Z); s.zbT = tb(Z * Bp);
-    s.gy = tb(B * D); s.gyT = tb(D * Bp);
-    s.gmu = tb(B * Z); s.gmuT = tb(Z * Bp); s.glv = tb(B * Z); s.glvT = tb(Z * Bp);
-    s.ohT = tb(8 * Bp);
+    for (int k = 0; k < 12; ++k) *hs[k] = tb(B * H);
+    s.zb = tb(B * Z);
+    s.gy = tb(B * D);
+    s.gmu = tb(B * Z); s.glv = tb(B * Z);
+    s.oh = tb(8 * B);
     s.gz = tf(B * Z); s.gmu_f = tf(B * Z); s.glv_f = tf(B * Z);
     s.kl_partials = tf((size_t)reparam_blocks(B * Z));
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));
@@ -108,8 +108,7 @@ size_t psvae_bf16_scratch_bytes(const psvae_dims* dims) {
 }
 
 // One training pass in bf16 (config 3).  x, params, grads, loss3, x_hat, mu, logvar are fp32; every
-// intermediate lives in `scratch` (psvae_bf16_scratch_bytes; MUST be zero-filled once by the caller: the
-// batch padding of the transposed copies is read but never written).  D and Z must be multiples of 32.
+// intermediate lives in `scratch` (psvae_bf16_scratch_bytes).  D and Z must be multiples of 32.
 // mode: 1 = forward (everything up to x_hat, the MSE gradient and the loss partial sums), 2 = backward, 3 = both
 static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                      const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
@@ -142,27 +141,27 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             src[k] = P[2 * k]; dst[k] = sc.Wb[k]; dstT[k] = sc.WbT[k];
             R[k] = wo[k]; C[k] = wi[k]; ld[k] = wi[k]; ldt[k] = wo[k];
         }
-        src[9] = x; dst[9] = sc.xb; dstT[9] = sc.xbT; R[9] = B; C[9] = D; ld[9] = D; ldt[9] = Bp;
-        // (+ the transposed one-hot label matrix for the conditional-table gradients, as rider blocks)
+        src[9] = x; dst[9] = sc.xb; dstT[9] = nullptr; R[9] = B; C[9] = D; ld[9] = D; ldt[9] = 0;
+        // (+ the one-hot label matrix for the conditional-table gradients, as rider blocks)
         RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
-                                     has_cond ? cond->age : nullptr, has_cond ? sc.ohT : nullptr, B, Bp));
+                                     has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
     }
-    auto hidden = [&](const u16* A, int K, int wk, u16* out, u16* outT, const float* ctab) {
+    auto hidden = [&](const u16* A, int K, int wk, u16* out, const float* ctab) {
         GemmDescBf d = bdesc(B, H, K, A, K, sc.Wb[wk], K);
-        d.bias = P[2 * wk + 1]; d.epi = BEPI_RELU; d.Cb = out; d.ldcb = H; d.CbT = outT; d.ldt = Bp;
+        d.bias = P[2 * wk + 1]; d.epi = BEPI_RELU; d.Cb = out; d.ldcb = H;
         if (ctab) { d.ctab = ctab; d.gender = cond->gender; d.age = cond->age; }
         return d;
     };
     {  // encoder layer 1 (model.py:15,23)
         GemmBatchBf b{};
-        addb(b, hidden(sc.xb, D, 0, sc.h1m, sc.h1mT, has_cond ? cond->tab[0] : nullptr));
-        addb(b, hidden(sc.xb, D, 3, sc.h1s, sc.h1sT, has_cond ? cond->tab[1] : nullptr));
+        addb(b, hidden(sc.xb, D, 0, sc.h1m, has_cond ? cond->tab[0] : nullptr));
+        addb(b, hidden(sc.xb, D, 3, sc.h1s, has_cond ? cond->tab[1] : nullptr));
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, hidden(sc.h1m, H, 1, sc.h2m, sc.h2mT, nullptr));
-        addb(b, hidden(sc.h1s, H, 4, sc.h2s, sc.h2sT, nullptr));
+        addb(b, hidden(sc.h1m, H, 1, sc.h2m, nullptr));
+        addb(b, hidden(sc.h1s, H, 4, sc.h2s, nullptr));
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {  // heads: fp32 outputs
@@ -174,27 +173,27 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         addb(b, dm); addb(b, ds);
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
-    // reparameterisation + KL partials; the kernel also writes z in both bf16 layouts (no cast/transpose launch)
+    // reparameterisation + KL partials; the kernel also writes z as bf16 (no cast launch)
     RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
-                             (int64_t)B * Z, s, sc.zb, sc.zbT, Z, Bp));
+                             (int64_t)B * Z, s, sc.zb));
     {
         GemmBatchBf b{};
-        addb(b, hidden(sc.zb, Z, 6, sc.d1, sc.d1T, has_cond ? cond->tab[2] : nullptr));
+        addb(b, hidden(sc.zb, Z, 6, sc.d1, has_cond ? cond->tab[2] : nullptr));
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, hidden(sc.d1, H, 7, sc.d2, sc.d2T, nullptr));
+        addb(b, hidden(sc.d1, H, 7, sc.d2, nullptr));
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     if (!bwd)  // forward-only call: the backward call sums ALL partial slots, so the unused ones must be zero
         RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
-    {  // decoder output (fp32) + MSE gradient (bf16, both layouts) + MSE partial sums
+    {  // decoder output (fp32) + MSE gradient (bf16) + MSE partial sums
         GemmBatchBf b{};
         GemmDescBf d = bdesc(B, D, H, sc.d2, H, sc.Wb[8], H);
         d.bias = P[17]; d.Cf = x_hat; d.ldcf = D; d.epi = BEPI_RECON; d.target = x; d.go = grad_loss;
         d.scale = 2.0f / (10.0f * (float)B * (float)D);
-        d.Cb = sc.gy; d.ldcb = D; d.CbT = sc.gyT; d.ldt = Bp; d.partials = sc.recon_partials;
+        d.Cb = sc.gy; d.ldcb = D; d.partials = sc.recon_partials;
         addb(b, d);
         RET_IF(launch_gemm_batch_bf16(b, s));
         n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
@@ -202,14 +201,16 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     }
     }
     if (!bwd) return 0;
-    // backward: wgrad  dW[o][i] = sum_b dY^T[o][b] X^T[i][b]  (A = dY^T [out,Bp], B = X^T [in,Bp], fp32 out, colsum = db)
-    //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]     (A = dY [B,out],  B = W^T [in,out], masked, both bf16 layouts)
-    const int S = bf_wgrad_split(Bp);  // 0: small batch, 64x64 tiles with the k split inside the workgroup
+    // backward: wgrad  dW[o][i] = sum_b dY[b][o] X[b][i]   (A = dY [B,out], B = X [B,in]: both batch-major, read transposed
+    //                                                       out of the staged LDS tiles; fp32 out, colsum = db)
+    //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]  (A = dY [B,out], B = W^T [in,out], masked, bf16 out)
+    const int S = bf_wgrad_split(B);
     const float* rsrc[24]; float* rdst[24]; int64_t rnum[24]; int rS[24]; int nred = 0;
-    auto wgrad = [&](const u16* dYT, int out_, const u16* XT, int in_, float* dW, float* db, float* slabW, float* slabB) {
-        GemmDescBf d = bdesc(out_, in_, Bp, dYT, Bp, XT, Bp);
+    auto wgrad = [&](const u16* dY, int out_, int ldy, const u16* X, int in_, float* dW, float* db, float* slabW, float* slabB) {
+        GemmDescBf d = bdesc(out_, in_, B, dY, ldy, X, in_);
+        d.tr = 1;
         d.ldcf = in_;
-        if (S > 0) {
+        if (S > 1) {
             d.ksplit = S;
             d.Cf = slabW; d.colsum = db ? slabB : nullptr;
             rsrc[nred] = slabW; rdst[nred] = dW; rnum[nred] = (int64_t)out_ * in_; rS[nred++] = S;
@@ -219,70 +220,69 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         }
         return d;
     };
-    auto dgrad = [&](const u16* dY, int out_, int wk, int in_, u16* dX, u16* dXT, const u16* act) {
+    auto dgrad = [&](const u16* dY, int out_, int wk, int in_, u16* dX, const u16* act) {
         GemmDescBf d = bdesc(B, in_, out_, dY, out_, sc.WbT[wk], out_);
-        d.Cb = dX; d.ldcb = in_; d.CbT = dXT; d.ldt = Bp;
+        d.Cb = dX; d.ldcb = in_;
         if (act) { d.epi = BEPI_MASK; d.mask = act; d.ldmask = in_; }
         return d;
     };
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.gyT, D, sc.d2T, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
-        addb(b, dgrad(sc.gy, D, 8, H, sc.dd2, sc.dd2T, sc.d2));
-        b.force_staged = S > 0;
+        addb(b, wgrad(sc.gy, D, D, sc.d2, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
+        addb(b, dgrad(sc.gy, D, 8, H, sc.dd2, sc.d2));
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dd2T, H, sc.d1T, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
-        addb(b, dgrad(sc.dd2, H, 7, H, sc.dd1, sc.dd1T, sc.d1));
-        b.force_staged = S > 0;
+        addb(b, wgrad(sc.dd2, H, H, sc.d1, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
+        addb(b, dgrad(sc.dd2, H, 7, H, sc.dd1, sc.d1));
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dd1T, H, sc.zbT, Z, G[12], G[13], sc.slab_w[6], sc.slab_b[6]));
-        if (has_cond) addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dd1T, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));  // table grad
+        addb(b, wgrad(sc.dd1, H, H, sc.zb, Z, G[12], G[13], sc.slab_w[6], sc.slab_b[6]));
+        if (has_cond) addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dd1, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));  // table grad
         GemmDescBf gz = bdesc(B, Z, H, sc.dd1, H, sc.WbT[6], H);  // g_z in fp32
         gz.Cf = sc.gz; gz.ldcf = Z;
         addb(b, gz);
-        b.force_staged = S > 0;
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
-    {   // g_mu / g_logvar (+ loss finalize, rng advance); the kernel also writes them in both bf16 layouts
+    {   // g_mu / g_logvar (+ loss finalize, rng advance); the kernel also writes their bf16 copies
         u16* rm[2] = {sc.gmu, sc.glv};
-        u16* tr[2] = {sc.gmuT, sc.glvT};
         RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
                                         sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
-                                        eps_in ? nullptr : rng_state, s, rm, tr, Bp));
+                                        eps_in ? nullptr : rng_state, s, rm));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.gmuT, Z, sc.h2mT, H, G[4], G[5], sc.slab_w[2], sc.slab_b[2]));
-        addb(b, wgrad(sc.glvT, Z, sc.h2sT, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
-        addb(b, dgrad(sc.gmu, Z, 2, H, sc.dh2m, sc.dh2mT, sc.h2m));
-        addb(b, dgrad(sc.glv, Z, 5, H, sc.dh2s, sc.dh2sT, sc.h2s));
-        b.force_staged = S > 0;
+        addb(b, wgrad(sc.gmu, Z, Z, sc.h2m, H, G[4], G[5], sc.slab_w[2], sc.slab_b[2]));
+        addb(b, wgrad(sc.glv, Z, Z, sc.h2s, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
+        addb(b, dgrad(sc.gmu, Z, 2, H, sc.dh2m, sc.h2m));
+        addb(b, dgrad(sc.glv, Z, 5, H, sc.dh2s, sc.h2s));
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dh2mT, H, sc.h1mT, H, G[2], G[3], sc.slab_w[1], sc.slab_b[1]));
-        addb(b, wgrad(sc.dh2sT, H, sc.h1sT, H, G[8], G[9], sc.slab_w[4], sc.slab_b[4]));
-        addb(b, dgrad(sc.dh2m, H, 1, H, sc.dh1m, sc.dh1mT, sc.h1m));
-        addb(b, dgrad(sc.dh2s, H, 4, H, sc.dh1s, sc.dh1sT, sc.h1s));
-        b.force_staged = S > 0;
+        addb(b, wgrad(sc.dh2m, H, H, sc.h1m, H, G[2], G[3], sc.slab_w[1], sc.slab_b[1]));
+        addb(b, wgrad(sc.dh2s, H, H, sc.h1s, H, G[8], G[9], sc.slab_w[4], sc.slab_b[4]));
+        addb(b, dgrad(sc.dh2m, H, 1, H, sc.dh1m, sc.h1m));
+        addb(b, dgrad(sc.dh2s, H, 4, H, sc.dh1s, sc.h1s));
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
-        addb(b, wgrad(sc.dh1mT, H, sc.xbT, D, G[0], G[1], sc.slab_w[0], sc.slab_b[0]));
-        addb(b, wgrad(sc.dh1sT, H, sc.xbT, D, G[6], G[7], sc.slab_w[3], sc.slab_b[3]));
+        addb(b, wgrad(sc.dh1m, H, H, sc.xb, D, G[0], G[1], sc.slab_w[0], sc.slab_b[0]));
+        addb(b, wgrad(sc.dh1s, H, H, sc.xb, D, G[6], G[7], sc.slab_w[3], sc.slab_b[3]));
         if (has_cond) {  // gtab[c][n] = sum_b onehot[b][c] dh1[b][n]: two more wgrad problems in this launch
-            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1mT, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
-            addb(b, wgrad(sc.ohT, PSVAE_COND_DIM, sc.dh1sT, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
+            addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1m, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
+            addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
         }
-        b.force_staged = S > 0;
+        b.force_staged = 1;
         RET_IF(launch_gemm_batch_bf16(b, s));
     }
     if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));

@@ -120,7 +120,6 @@ struct GemmDescBf {
     const unsigned short* B;     // bf16 [N, ldb], k contiguous
     float* Cf;                   // nullable: fp32 output [M, ldcf]
     unsigned short* Cb;          // nullable: bf16 output [M, ldcb]
-    unsigned short* CbT;         // nullable: bf16 transposed output [N, ldt]
     const float* bias;           // nullable: fp32 [N]
     const unsigned short* mask;  // BEPI_MASK: saved bf16 activation [M, ldmask]
     const float* target;         // BEPI_RECON: fp32 x [M, ldcf]
@@ -134,7 +133,9 @@ struct GemmDescBf {
     int M, N, K;                 // K % 32 == 0
     int ksplit;                  // > 1 (LDS-staged 128x128 kernel only): the k range is cut over `ksplit` workgroups; slice s
                                  // writes its partial fp32 tile to Cf + s*M*ldcf and partial column sums to colsum + s*M
-    int lda, ldb, ldcf, ldcb, ldt, ldmask;
+    int lda, ldb, ldcf, ldcb, ldmask;
+    int tr;                      // 1 (LDS-staged kernel only): both operands are k-MAJOR in memory -- A is [K, lda] with M valid
+                                 // columns, B is [K, ldb] with N (weight gradients: K = batch rows, any K; pitches % 8 == 0)
     int epi;
     int tiles_m, tiles_n, tile_begin;
 };
@@ -143,13 +144,13 @@ struct GemmBatchBf {
     int n;
     int total_tiles;
     int force_staged;  // host-side: 1 = launch with the LDS-staged 128x128 kernel whatever the tile count
+    int xcd_remap;     // 1: XCD-aware tile order inside each problem (set by the launcher)
 };
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream);
 hipError_t launch_cast_transpose(const float* const* src, unsigned short* const* dst, unsigned short* const* dstT,
                                  const int* R, const int* C, const int* ld, const int* ldt, int n, hipStream_t s,
                                  const int32_t* gender = nullptr, const int32_t* age = nullptr,
-                                 unsigned short* ohT = nullptr, int B = 0, int Bp = 0);
-hipError_t launch_onehot_t(const int32_t* gender, const int32_t* age, unsigned short* ohT, int B, int Bp, hipStream_t s);
+                                 unsigned short* oh = nullptr, int B = 0);  // oh: one-hot label matrix [B][8] (rider blocks)
 hipError_t launch_cond_colsum_bf16(const unsigned short* const* dY, float* const* gtab, int nprob,
                                    const int32_t* gender, const int32_t* age, int B, int N, hipStream_t s);
 
@@ -229,8 +230,7 @@ hipError_t launch_adam_dual(const psvae_adam_dev* L, psvae_adam_state* st, doubl
                             double gscale, hipStream_t s);
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
                              uint64_t seed, uint64_t offset, float* eps_out, float* z, float* kl_partials,
-                             int64_t n, hipStream_t s, unsigned short* zb = nullptr, unsigned short* zbT = nullptr,
-                             int Z = 0, int Bp = 0);  // zb / zbT: optional bf16 copies of z, [B,Z] and [Z,Bp]
+                             int64_t n, hipStream_t s, unsigned short* zb = nullptr);  // zb: optional bf16 copy of z [B,Z]
 // row L2 normalise: xh = y / max(||y||, 1e-12), ynorm = that max
 hipError_t launch_normalize_rows(const float* y, float* xh, float* ynorm, int B, int D, hipStream_t s);
 // loss3 = {total, recon, kl}
@@ -253,8 +253,7 @@ hipError_t launch_reparam_bwd_final(const float* g_z, const float* mu, const flo
                                     float beta, const float* go, float* g_mu, float* g_lv, int B, int Z, int D,
                                     const float* kl_partials, int n_kl, const float* recon_partials, int n_recon,
                                     float* loss3, uint64_t* rng, hipStream_t s,
-                                    unsigned short* const* bf_rm = nullptr, unsigned short* const* bf_tr = nullptr,
-                                    int Bp = 0);  // bf_rm / bf_tr: optional bf16 copies of {g_mu, g_lv}: [B,Z] / [Z,Bp]
+                                    unsigned short* const* bf_rm = nullptr);  // optional bf16 copies of {g_mu, g_lv} [B,Z]
 // gtab[i][c][n] = sum_{b: label_b = c} dY[i][b][n] for up to 3 problems (conditional-table gradients)
 hipError_t launch_cond_colsum(const float* const* dY, float* const* gtab, int nprob, const int32_t* gender,
                               const int32_t* age, int B, int N, hipStream_t s);

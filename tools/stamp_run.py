@@ -1,0 +1,11 @@
+import sys, torch
+sys.path.insert(0, ".")
+from pseudo_speaker_vae_amd.engine import TrainEngine
+B, D, Z = 4096, 256, 64
+eng = TrainEngine(D, Z, B, device="cuda:0", seed=0, dtype="bf16", conditional=True)
+g = torch.Generator().manual_seed(1)
+x = torch.randn(B, D, generator=g).cuda()
+eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
+for _ in range(3):
+    eng.forward_backward(x)
+torch.cuda.synchronize()
