@@ -159,6 +159,21 @@ def launch_children(args) -> int:
 # --------------------------------------------------------------------------------------------------------------
 # one rank
 # --------------------------------------------------------------------------------------------------------------
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the result line must be the only
+    thing on stdout, so file descriptor 1 points at stderr while the process group is initialised and warmed up"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class Rank:
     """process-group plumbing of one rank: init, fence (barrier + device sync), max over ranks, teardown"""
 
@@ -178,11 +193,15 @@ class Rank:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            if self.stub:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=self.dev)
-            self.pg = dist.group.WORLD
+            with _StdoutToStderr():
+                if self.stub:
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev)
+                self.pg = dist.group.WORLD
+                dist.barrier()  # brings the communicator up (and its banner out) now
+                if not self.stub:
+                    torch.cuda.synchronize(self.dev)
 
     def barrier(self):
         if self.use_dist:

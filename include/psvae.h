@@ -294,12 +294,12 @@ int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
  * maintains the k-major weight copies psvae_step_opts::params_kmajor points at.  The flat buffers share one layout:
  * mat_off/rows/cols = the 9 weight matrices ([rows, cols] = [out, in]) inside them, the k-major copy of matrix k lives
  * at the same offset of param_kmajor as [cols, rows]; vec_off/len = every other trained range (biases, conditional
- * tables).  *state must be zero-initialised except lr.  One launch. */
+ * tables).  *state must be zero-initialised except lr.  Two launches (a one-thread tick of the step counter, then the
+ * update). */
 typedef struct psvae_adam_state {
     double lr;
-    int64_t step;   /* completed optimizer steps; advanced by the kernel */
-    uint32_t ticket; /* internal (0 between launches) */
-    uint32_t pad;
+    int64_t step;   /* completed optimizer steps; advanced on the device by every call */
+    uint32_t reserved[2];
 } psvae_adam_state;
 typedef struct psvae_adam_dev {
     float* param;

@@ -55,8 +55,8 @@ class StepOpts(C.Structure):
     _fields_ = [("params_kmajor", C.POINTER(Params)), ("cond", C.POINTER(Cond)), ("flags", C.c_uint32)]
 
 
-class AdamState(C.Structure):  # device-resident: lr, completed steps, the kernel's ticket
-    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("ticket", C.c_uint32), ("pad", C.c_uint32)]
+class AdamState(C.Structure):  # device-resident: lr, completed steps
+    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("reserved", C.c_uint32 * 2)]
 
 
 class AdamDev(C.Structure):

@@ -361,8 +361,10 @@ hipError_t launch_recon_row(const float* y, const float* x, float* xh, float* yn
 // Adam with device-resident {lr, step} that ALSO maintains the k-major ([in, out]) copies of the weight matrices the
 // forward GEMMs read (lightning.py:205; torch.optim.Adam, non-amsgrad).  One launch over 32 x 32 tiles of the nine
 // weight matrices (row-major update, transposed through LDS, whole 128-B rows both ways) plus 1024-element chunks of
-// every other trained range.  The step counter lives on the device and is advanced by the LAST workgroup to finish (a
-// ticket), after every workgroup has read it: a captured HIP graph applies the right bias correction on every replay.
+// every other trained range.  The step counter lives on the device: a one-thread tick launch in front advances it, the
+// main launch only reads it -- a captured HIP graph applies the right bias correction on every replay.  (A ticket inside
+// the main kernel -- last workgroup to finish advances the counter -- was measured first: 1,300 workgroups taking an
+// atomic ticket on one word behind a device-scope fence each cost 45 us per step; the tick launch costs 2.)
 // ---------------------------------------------------------------------------------------------------------------
 struct AdamDevArgs {
     float* p; float* pT; const float* g; float* m; float* v;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256) void adam_dual_kernel(const AdamDevArgs a) {
     const int tid = threadIdx.x;
     if (tid == 0) {
         const double lr = a.st->lr;
-        const double t = (double)(a.st->step + 1);
+        const double t = (double)a.st->step;  // already advanced by adam_tick_kernel
         const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
         s_hyper[0] = (float)(lr / bc1);
         s_hyper[1] = (float)(1.0 / sqrt(bc2));
@@ -436,18 +438,9 @@ __global__ __launch_bounds__(256) void adam_dual_kernel(const AdamDevArgs a) {
             if (e < a.vec_len[k]) upd(a.vec_off[k] + e);
         }
     }
-    // ticket: the last workgroup to get here advances the step (every workgroup read it before taking its ticket)
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const unsigned prev = atomicAdd(&a.st->ticket, 1u);
-        if (prev == (unsigned)gridDim.x - 1u) {
-            a.st->step += 1;
-            a.st->ticket = 0u;
-            __threadfence();
-        }
-    }
 }
+
+__global__ void adam_tick_kernel(psvae_adam_state* st) { st->step += 1; }
 
 hipError_t launch_adam_dual(const psvae_adam_dev* L, psvae_adam_state* st, double b1, double b2, double eps, double wd,
                             double gscale, hipStream_t s) {
@@ -470,6 +463,7 @@ hipError_t launch_adam_dual(const psvae_adam_dev* L, psvae_adam_state* st, doubl
     }
     a.total_blocks = t + vb;
     a.st = st; a.b1 = b1; a.b2 = b2; a.eps = (float)eps; a.wd = (float)wd; a.gscale = (float)gscale;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, st);
     hipLaunchKernelGGL(adam_dual_kernel, dim3(a.total_blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }

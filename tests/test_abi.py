@@ -99,7 +99,7 @@ int main(void) {
                              PSVAE_PHASE_ALL, NULL, NULL) != PSVAE_ERR_NULL) return 6;
     {
         psvae_step_opts o = {NULL, NULL, PSVAE_COS_LOSS};
-        psvae_adam_state st = {1e-3, 0, 0u, 0u};
+        psvae_adam_state st = {1e-3, 0, {0u, 0u}};
         if (o.flags != 2u || sizeof st != 24 || psvae_last_step_launches() != 0) return 7;
         if (psvae_adam_step_dev_f32(NULL, NULL, 0.9, 0.999, 1e-8, 0.0, 1.0, NULL) != PSVAE_ERR_NULL) return 8;
         if (psvae_transpose_params_f32(&d, NULL, NULL, NULL) != PSVAE_ERR_NULL) return 9;
