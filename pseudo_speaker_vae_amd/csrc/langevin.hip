@@ -4,8 +4,13 @@
 // of z and two .item() host syncs.  Here the whole chain of `num_steps` updates is ONE kernel: one lane
 // owns one latent row for its whole life (z and its gradient live in registers), the classifier weights
 // sit in LDS and are read as wave-uniform broadcasts, the noise comes from the same Philox4x32-10 stream as
-// the VAE's epsilon, nothing touches the host.  fp32 VALU FMAs run at the fp32 MFMA rate on gfx950, so
-// the matrix cores would not be faster for this 64 -> 128 -> C chain.
+// the VAE's epsilon, nothing touches the host.  That per-lane form (langevin_kernel) serves every supported shape.
+//
+// For heads with a hidden layer whose sizes are whole 16-blocks (the one the reference trains: 64 -> 128 -> C) the
+// chain runs on the matrix cores instead (langevin_mfma_kernel): fp32 MFMA and fp32 VALU have the same peak, but the
+// per-lane form leaves the 64 -> 128 layer as 2 x 8,192 SERIAL FMAs per lane and step fed by LDS broadcasts (13.6 % of
+// the vector peak measured, 195 ms for 1 M rows x 100 steps), while one wavefront per 16 rows does the same layer as
+// 2 x 128 MFMAs whose operands never leave the register file.
 //
 //   logits = W2 relu(W1 z + b1) + b2          (latent_classifier.py:30-40; or logits = W1 z + b1 when hidden == 0)
 //   grad   = d/dz [ log_softmax(logits)[target] - 0.5 |z|^2 ]                      (inference.py:56-93)
@@ -173,10 +178,184 @@ __global__ __launch_bounds__(256) void langevin_kernel(int64_t N, int hidden, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA form.  One wavefront owns 16 latent rows for the whole chain.  Everything is kept TRANSPOSED so that a row's data
+// stays in the lanes r = lane & 15 of its wavefront through both products (no LDS transposes, no shuffles but one):
+//   h^T  [hidden x 16 rows] = W1 [hidden x Z] . z^T [Z x 16]            A = W1 fragments,   B = z,   C init = b1
+//   gz^T [Z x 16 rows]      = W1^T [Z x hidden] . dh^T [hidden x 16]    A = W1^T fragments, B = dh,  C init = -z (prior)
+// v_mfma_f32_16x16x4_f32: lane (r, q) supplies A[i = r][k = q], B[k = q][n = r] and receives D[i = 4q + j][n = r], j < 4.
+// So lane (r, q) holds, for its row r: z / gz at features 16 m' + 4q + j (m' < ZB: 4 consecutive features = one Philox
+// block per m'), h / dh at hidden units 16 m + 4q + j (m < HB).  The contraction index of each product is enumerated in
+// exactly the order the lanes hold the B operand (k slot q of MFMA step (m', j) is feature 16 m' + 4q + j), and the A
+// fragments of W1 -- both orientations, 8 ZB HB registers -- are gathered ONCE per wavefront to match: the loop issues
+// nothing but MFMAs, the Philox / softmax / update VALU work and C x HB 16-byte LDS reads of W2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ZB, int HB>
+__global__ __launch_bounds__(256) void langevin_mfma_kernel(int64_t N, int C, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ W2,
+                                                            const float* __restrict__ b2, float* __restrict__ zio,
+                                                            int target, float step_size, float noise_weight,
+                                                            int64_t num_steps, const float* __restrict__ noises,
+                                                            uint64_t seed, uint64_t offset, float* __restrict__ history) {
+    constexpr int ZD = 16 * ZB, HD = 16 * HB;
+    __shared__ __attribute__((aligned(16))) float sW2[LV_MAXC * HD];
+    __shared__ float sb2[LV_MAXC];
+    for (int i = threadIdx.x; i < C * HD; i += 256) sW2[i] = W2[i];
+    if (threadIdx.x < C) sb2[threadIdx.x] = b2[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + r;
+    const bool live = row < N;
+    const int64_t rr = live ? row : N - 1;  // dead lanes shadow the last row (no stores)
+    // W1 fragments, gathered once: forward A[i = hidden 16m + r][k = feature 16m' + 4q + j'], backward
+    // A[i = feature 16m' + r][k = hidden 16m + 4q + j]
+    float wf[HB][4 * ZB], wb[ZB][4 * HB], bias1[HB][4];
+#pragma unroll
+    for (int m = 0; m < HB; ++m) {
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(W1 + (size_t)(16 * m + r) * ZD + 16 * mp + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[m][4 * mp + j] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias1[m][j] = b1[16 * m + 4 * q + j];
+    }
+#pragma unroll
+    for (int mp = 0; mp < ZB; ++mp)
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wb[mp][4 * m + j] = W1[(size_t)(16 * m + 4 * q + j) * ZD + 16 * mp + r];
+    float z[4 * ZB];
+#pragma unroll
+    for (int mp = 0; mp < ZB; ++mp) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(zio + rr * ZD + 16 * mp + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[4 * mp + j] = v[j];
+    }
+    const float drift = 0.5f * step_size * step_size, nsc = step_size * noise_weight;
+    const uint64_t blocks_per_step = (uint64_t)((N * ZD + 3) / 4);
+    for (int64_t t = 0; t < num_steps; ++t) {
+        // this step's noise first: it depends on nothing, so its VALU work can fill the MFMA shadows below
+        f32x4 nz[ZB];
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp) {
+            if (noises)
+                nz[mp] = *reinterpret_cast<const f32x4*>(noises + ((size_t)t * N + rr) * ZD + 16 * mp + 4 * q);
+            else
+                nz[mp] = normal4(offset + (uint64_t)t * blocks_per_step + (uint64_t)((rr * ZD + 16 * mp + 4 * q) >> 2), seed);
+        }
+        // ---- h^T = W1 z^T + b1 ----
+        f32x4 h[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) h[m] = f32x4{bias1[m][0], bias1[m][1], bias1[m][2], bias1[m][3]};
+#pragma unroll
+        for (int s = 0; s < 4 * ZB; ++s)
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m][s], z[s], h[m], 0, 0, 0);
+        // ---- logits: this lane's 4 HB hidden units, then the sum over the 4 lanes of the row ----
+        float logits[LV_MAXC];
+#pragma unroll
+        for (int c = 0; c < LV_MAXC; ++c) logits[c] = 0.f;
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[m][j] = fmaxf(h[m][j], 0.f);  // (mask = h > 0)
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c)
+                if (c < C) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + c * HD + 16 * m + 4 * q);
+                    logits[c] = fmaf(w[0], h[m][0], fmaf(w[1], h[m][1], fmaf(w[2], h[m][2], fmaf(w[3], h[m][3], logits[c]))));
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < LV_MAXC; ++c)
+            if (c < C) {
+                logits[c] += __shfl_xor(logits[c], 16);
+                logits[c] += __shfl_xor(logits[c], 32);
+                logits[c] += sb2[c];
+            }
+        // d log_softmax[target] / d logits = onehot(target) - softmax(logits)     (inference.py:56-70)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < LV_MAXC; ++c)
+            if (c < C) mx = fmaxf(mx, logits[c]);
+        float den = 0.f, gl[LV_MAXC];
+#pragma unroll
+        for (int c = 0; c < LV_MAXC; ++c) {
+            gl[c] = c < C ? expf(logits[c] - mx) : 0.f;
+            den += gl[c];
+        }
+#pragma unroll
+        for (int c = 0; c < LV_MAXC; ++c) gl[c] = (c == target ? 1.f : 0.f) - gl[c] / den;
+        if (C == 1) gl[0] = 0.f;  // log_softmax over one logit is identically 0 (inference.py:60-66 as written)
+        // ---- dh = (W2^T gl) * [h > 0]  (in place of h) ----
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c)
+                if (c < C) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + c * HD + 16 * m + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = fmaf(w[j], gl[c], g[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[m][j] = h[m][j] > 0.f ? g[j] : 0.f;
+        }
+        // ---- gz^T = W1^T dh^T - z ----
+        f32x4 gz[ZB];
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp) gz[mp] = f32x4{-z[4 * mp], -z[4 * mp + 1], -z[4 * mp + 2], -z[4 * mp + 3]};
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mp = 0; mp < ZB; ++mp)
+                    gz[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[mp][4 * m + j], h[m][j], gz[mp], 0, 0, 0);
+        // ---- update (inference.py:95-97) ----
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[4 * mp + j] += drift * gz[mp][j] + nsc * nz[mp][j];
+            if (history && live)
+                *reinterpret_cast<f32x4*>(history + ((size_t)t * N + row) * ZD + 16 * mp + 4 * q) =
+                    f32x4{z[4 * mp], z[4 * mp + 1], z[4 * mp + 2], z[4 * mp + 3]};
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp)
+            *reinterpret_cast<f32x4*>(zio + row * ZD + 16 * mp + 4 * q) = f32x4{z[4 * mp], z[4 * mp + 1], z[4 * mp + 2], z[4 * mp + 3]};
+    }
+}
+
+template <int ZB, int HB>
+static hipError_t launch_langevin_mfma(int64_t N, int C, const float* W1, const float* b1, const float* W2, const float* b2,
+                                       float* z, int target, float step_size, float noise_weight, int64_t num_steps,
+                                       const float* noises, uint64_t seed, uint64_t offset, float* history, hipStream_t s) {
+    const int grid = (int)((N + 63) / 64);
+    hipLaunchKernelGGL((langevin_mfma_kernel<ZB, HB>), dim3(grid), dim3(256), 0, s, N, C, W1, b1, W2, b2, z, target,
+                       step_size, noise_weight, num_steps, noises, seed, offset, history);
+    return hipGetLastError();
+}
+
 hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1, const float* b1, const float* W2,
                            const float* b2, float* z, int target, float step_size, float noise_weight,
                            int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
                            hipStream_t s) {
+    // heads whose two sizes are whole 16-blocks and whose W1 fragments fit the register file run on the matrix cores
+    static const bool mfma_on = getenv("PSVAE_LANGEVIN_VALU") == nullptr;
+    if (mfma_on && hidden > 0 && (reinterpret_cast<uintptr_t>(W1) & 15) == 0) {
+#define PSVAE_LVM(ZB, HB)                                                                                           \
+    if (Z == 16 * ZB && hidden == 16 * HB)                                                                          \
+        return launch_langevin_mfma<ZB, HB>(N, C, W1, b1, W2, b2, z, target, step_size, noise_weight, num_steps,    \
+                                            noises, seed, offset, history, s);
+        PSVAE_LVM(4, 8) PSVAE_LVM(4, 4) PSVAE_LVM(2, 8) PSVAE_LVM(2, 4) PSVAE_LVM(8, 4) PSVAE_LVM(1, 8)
+#undef PSVAE_LVM
+    }
     const int rows1 = hidden > 0 ? hidden : C;
     const size_t lds = (size_t)(rows1 * Z + ((rows1 + 3) & ~3) + C * hidden + 8) * sizeof(float);
     const int grid = (int)((N + 255) / 256);
