@@ -143,6 +143,19 @@ std::mutex g_tune_mu;
 thread_local int t_launches = 0;       // launches issued by this thread's current / last psvae_train_step_f32
 constexpr int STAGE2_SLABS = H / 64;   // partial products per row tile when a 512-wide layer is cut in 64-column tiles
 
+// Which of the two second-stage folds a (B, Z) step uses: bit 0 = the heads ride on encoder layer 1's launch, bit 1 =
+// decoder.0's dgrad rides on decoder.2's.  Measured (tools/stage2_shapes.sh, tuned plans, same box): at Z = 64 and
+// B = 1024 the folded 10-launch step wins (136.2-137.6 vs 137.7-138.7 us); at B = 2048 it is a tie (212.6 vs 212.3), at
+// B = 4096 it loses (367-369 vs 357 us) and at Z = 128 it loses clearly (175 vs 160 us: twice the slab bytes and two
+// column groups per second stage) -- so it is on for Z = 64, B <= 2048.  PSVAE_STAGE2=mask overrides (experiments).
+inline int stage2_mask(int64_t B, int64_t Z) {
+    const char* e = getenv("PSVAE_STAGE2");  // (read per call: tests and A/B scripts flip it in-process)
+    const int env = getenv("PSVAE_NO_STAGE2") ? 0 : (e ? atoi(e) : -1);
+    if ((Z & 63) != 0 || Z > 128) return 0;
+    if (env >= 0) return env & 3;
+    return (Z == 64 && B <= 2048) ? 3 : 0;
+}
+
 bool find_plan(int64_t B, int64_t D, int64_t Z, StepPlan* out) {
     if (t_trial) { *out = *t_trial; return true; }
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -488,11 +501,9 @@ int psvae_train_step_f32(const psvae_dims* dims, const float* x, const psvae_par
     const void* al[] = {mu, logvar, eps_in, acts->eps, acts->z, acts->d1, P[12], P[13], P[5], P[11], sc.gmu, sc.glv,
                         acts->h2m, acts->h2s};
     const bool bn_ok = reparam_linear_ok(Z, H, al, 14);
-    // PSVAE_STAGE2: bit 0 = the heads ride on encoder layer 1's launch, bit 1 = decoder.0's dgrad rides on decoder.2's
-    static const int stage2_mask = getenv("PSVAE_NO_STAGE2") ? 0 : (getenv("PSVAE_STAGE2") ? atoi(getenv("PSVAE_STAGE2")) : 3);
     static const bool bottleneck_on = getenv("PSVAE_NO_BOTTLENECK") == nullptr;
-    const bool fuse_ok = bottleneck_on && kmajor_w && bn_ok && (Z & 63) == 0 && Z <= 128;
-    const bool fuse_f = fuse_ok && (stage2_mask & 1), fuse = fuse_ok && (stage2_mask & 2);
+    const int s2mask = (bottleneck_on && kmajor_w && bn_ok) ? stage2_mask(B, Z) : 0;
+    const bool fuse_f = s2mask & 1, fuse = s2mask & 2;
     const bool all = phases == PSVAE_PHASE_ALL;
 
     // Which backward launch carries which weight gradient (fused single-call path): slot 1 = with decoder.4's dgrad,
@@ -774,16 +785,16 @@ int psvae_tune_train_step_f32(const psvae_dims* dims, const float* x, const psva
     static const signed char tn_c[] = {1, 2, 6, 8}, ot_c[] = {1, 2, 4, 6, 8, 7, 9};  // 7, 9: launches without wgrads only
     // which launch sites exist in this configuration (mirrors psvae_train_step_f32)
     const bool bn = getenv("PSVAE_NO_BOTTLENECK") == nullptr && (dims->Z & 15) == 0 && dims->Z <= 128;
-    const bool fuse = bn && getenv("PSVAE_NO_STAGE2") == nullptr && getenv("PSVAE_FWD_NT") == nullptr &&
-                      (dims->Z & 63) == 0;
+    const int s2mask = (bn && getenv("PSVAE_FWD_NT") == nullptr) ? stage2_mask(dims->B, dims->Z) : 0;
+    const bool fuse_f = s2mask & 1, fuse = s2mask & 2;
     for (int pass = 0; pass < 2 && rc == 0; ++pass) {
         for (int site = 0; site < NSITE && rc == 0; ++site) {
             // decoder layer 0 normally runs inside the bottleneck kernel: its GEMM site has nothing to tune; with the
             // second-stage fusion the heads (F3), decoder.0's dgrad (B3) and the heads' dgrad (B4) have no launch either
             if (site == 3 && bn) continue;
-            if (fuse && (site == 2 || site == 8 || site == 9)) continue;
+            if ((fuse_f && site == 2) || (fuse && (site == 8 || site == 9))) continue;
             const bool has_tn = site >= 6, has_other = site != 11;
-            const bool s2 = fuse && (site == 1 || site == 7);  // second-stage launches: config 6 for the non-TN problems
+            const bool s2 = (fuse_f && site == 1) || (fuse && site == 7);  // second-stage launches: config 6 for the non-TN problems
             for (int a = 0; a < (has_tn ? 4 : 1) && rc == 0; ++a)
                 for (int o = s2 ? 3 : 0; o < (s2 ? 4 : (has_other ? 7 : 1)) && rc == 0; ++o) {
                     // beside weight gradients only the compiled mixed pairs exist: <tn, 9> for tn in {2, 6}, never 7

@@ -45,11 +45,12 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize("D,Z,B,launches", [(256, 64, 1024, 10), (512, 128, 1024, 10), (256, 64, 37, 10),
-                                            (256, 64, 4096, 10), (256, 32, 64, 12), (96, 24, 11, 13)])
+@pytest.mark.parametrize("D,Z,B,launches", [(256, 64, 1024, 10), (512, 128, 1024, 12), (256, 64, 37, 10),
+                                            (256, 64, 4096, 12), (256, 32, 64, 12), (96, 24, 11, 13)])
 def test_launch_count_and_parity_with_optimizer_maintained_kmajor_weights(ops, D, Z, B, launches):
-    """cfg2 / cfg4 / cfg1 shapes: TEN launches when Z is a multiple of 64 (twelve otherwise: separate heads and
-    decoder.0-dgrad launches; thirteen when Z is not a multiple of 16: no bottleneck kernel), same numbers as the oracle"""
+    """cfg2 / cfg4 / cfg1 shapes: TEN launches at Z = 64, B <= 2048 (where the second-stage folds were measured to win),
+    twelve otherwise (separate heads and decoder.0-dgrad launches), thirteen when Z is not a multiple of 16 (no
+    bottleneck kernel): same numbers as the oracle everywhere"""
     p = O.init_params(D, Z, 5)
     torch.manual_seed(D + B)
     x, eps = torch.randn(B, D), torch.randn(B, Z)
@@ -62,6 +63,26 @@ def test_launch_count_and_parity_with_optimizer_maintained_kmajor_weights(ops, D
     assert_close(r["ws"].acts["z"], oacts["z"], REL_TOL, "z")
     for i, k in enumerate(("total", "recon", "kl")):
         assert abs(float(r["loss3"][i]) - float(losses[k])) <= REL_TOL * max(1.0, abs(float(losses[k]))), k
+    for k, g in zip(O.PARAM_KEYS, r["grads"]):
+        assert_close(g, ograds[k], REL_TOL, "grad " + k)
+
+
+@pytest.mark.parametrize("D,Z,B,mask,launches", [(512, 128, 1024, "3", 10), (256, 64, 4096, "3", 10), (256, 64, 1024, "0", 12),
+                                                 (256, 64, 1024, "1", 11), (256, 64, 1024, "2", 11)])
+def test_second_stage_folds_forced_on_and_off_keep_parity(ops, monkeypatch, D, Z, B, mask, launches):
+    """PSVAE_STAGE2 forces the folds where the default policy leaves them off (Z = 128: two column groups per second
+    stage; B = 4096: 1024 tiles per launch, not the persistent kernel) and off where it has them on: every
+    combination computes the oracle's numbers"""
+    monkeypatch.setenv("PSVAE_STAGE2", mask)
+    p = O.init_params(D, Z, 6)
+    torch.manual_seed(D + B + int(mask))
+    x, eps = torch.randn(B, D), torch.randn(B, Z)
+    r = _fused(ops, p, x, eps, 1.1)
+    assert r["launches"] == launches
+    losses, ograds, oacts, _ = O.train_step(p, x, eps, 1.1, masks=r["masks"])
+    check_masks(r["masks"], oacts)
+    assert_close(r["outs"][1], oacts["mu"], REL_TOL, "mu")
+    assert abs(float(r["loss3"][0]) - float(losses["total"])) <= REL_TOL * max(1.0, abs(float(losses["total"])))
     for k, g in zip(O.PARAM_KEYS, r["grads"]):
         assert_close(g, ograds[k], REL_TOL, "grad " + k)
 
@@ -112,7 +133,7 @@ def test_loss_variants_inside_the_fused_step(ops, variant, D, Z, B):
     torch.manual_seed(B)
     x, eps = torch.randn(B, D), torch.randn(B, Z)
     r = _fused(ops, p, x, eps, 0.8, flags=flags, go=0.37)
-    assert r["launches"] == (11 if Z % 64 == 0 else 13)
+    assert r["launches"] == (11 if Z == 64 else 13)
     losses, ograds, oacts, _ = O.train_step(p, x, eps, 0.8, normalize, cos, go=0.37, masks=r["masks"])
     check_masks(r["masks"], oacts)
     assert_close(r["outs"][0], oacts["x_hat"], REL_TOL, "x_hat")
