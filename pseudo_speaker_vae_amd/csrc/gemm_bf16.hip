@@ -83,25 +83,28 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
     const bool do_colsum = (d.colsum != nullptr) && (tn == 0) && (wn == 0);
 
     if constexpr (STAGED) {
-      static_assert(KS == 1 && WM == 2 && WN == 2 && TM == 4 && TN == 4, "staged loop: 128x128 tile, 2x2 waves");
+      static_assert(KS == 1 && WM == 2 && WN == 2 && TM == 4 && (TN == 4 || TN == 2), "staged loop: 128x128 or 128x64 tile, 2x2 waves");
+      constexpr int PB = BN / 32;  // staging passes of the B operand (A: 4); the 128x64 tile lets two workgroups share a CU
       typedef std::integral_constant<int, 0> I0;
       typedef std::integral_constant<int, 1> I1;
       if (d.tr) {
         // ---- k-MAJOR operands (weight gradients): A = dY [K rows = batch][M], B = X [K][N], row-major as produced.
         // LDS image [64 k][128 + 8] per operand and buffer; fragments come out transposed (see the file header).
-        constexpr int BK = 64, LSM = BM + 8;               // 272-B rows: every piece and every tr address 8-B aligned
+        constexpr int BK = 64, LSM = BM + 8, LSN = BN + 8;  // 272 / 144-B rows: every piece and tr address 8-B aligned
         typedef short v4s __attribute__((ext_vector_type(4)));
         u16* sA = reinterpret_cast<u16*>(smem);            // [2][BK][LSM]
-        u16* sB = sA + 2 * BK * LSM;                       // [2][BK][LSM]
-        const int krow = tid >> 4, mcol = (tid & 15) * 8;  // piece (k row, feature) of pass i: k = krow + 16 i
+        u16* sB = sA + 2 * BK * LSM;                       // [2][BK][LSN]
+        const int krow = tid >> 4, mcol = (tid & 15) * 8;  // A piece (k row, feature) of pass i: k = krow + 16 i
+        constexpr int NPB = BN / 8, KPB = 256 / NPB;       // B: pieces per k row, k rows per pass (PB passes)
+        const int krowb = tid / NPB, ncol = (tid % NPB) * 8;
         // a piece is fetched when it lies inside the row pitch (pitches are multiples of 8; columns between the valid
         // extent and the pitch are zero by construction: the one-hot label matrix); batch rows >= K read as zeros
-        const bool okA = m0 + mcol + 8 <= d.lda, okB = n0 + mcol + 8 <= d.ldb;
+        const bool okA = m0 + mcol + 8 <= d.lda, okB = n0 + ncol + 8 <= d.ldb;
         const u16* ga = A + (size_t)krow * d.lda + (okA ? m0 + mcol : 0);
-        const u16* gb = B + (size_t)krow * d.ldb + (okB ? n0 + mcol : 0);
+        const u16* gb = B + (size_t)krowb * d.ldb + (okB ? n0 + ncol : 0);
         // TWO k tiles in flight in registers (sets 0 / 1) on top of the two LDS buffers: with one the loop exposed a
         // full memory round trip per 64-row tile (the bf16 MFMAs of a tile take 0.2 us, the fetch ~2 us)
-        bf16x8 ra_[2][4], rb_[2][4];
+        bf16x8 ra_[2][4], rb_[2][PB];
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
         auto gload = [&](auto P, int t) {
             constexpr int p = decltype(P)::value;
@@ -110,16 +113,19 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
             for (int i = 0; i < 4; ++i) {
                 const bool in = k0 + krow + 16 * i < K;
                 ra_[p][i] = (in && okA) ? ldgb<bf16x8>(ga + (size_t)(k0 + 16 * i) * d.lda) : zero8;
-                rb_[p][i] = (in && okB) ? ldgb<bf16x8>(gb + (size_t)(k0 + 16 * i) * d.ldb) : zero8;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const bool in = k0 + krowb + KPB * i < K;
+                rb_[p][i] = (in && okB) ? ldgb<bf16x8>(gb + (size_t)(k0 + KPB * i) * d.ldb) : zero8;
             }
         };
         auto lstore = [&](auto P, int buf) {
             constexpr int p = decltype(P)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<bf16x8*>(sA + (buf * BK + krow + 16 * i) * LSM + mcol) = ra_[p][i];
-                *reinterpret_cast<bf16x8*>(sB + (buf * BK + krow + 16 * i) * LSM + mcol) = rb_[p][i];
-            }
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(sA + (buf * BK + krow + 16 * i) * LSM + mcol) = ra_[p][i];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<bf16x8*>(sB + (buf * BK + krowb + KPB * i) * LSN + ncol) = rb_[p][i];
         };
         const int nt_all = (K + BK - 1) / BK;
         const int S = d.ksplit > 1 ? d.ksplit : 1;
@@ -133,7 +139,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         STAMP();
         // lane (r, q) of the MFMA wants k = 32 s2 + 8 q + 0..7 of feature column r of its block: two transposed reads
         // of 4 k rows each; inside its 16-lane group the lane SUPPLIES the address of (k row r >> 2, features 4 (r & 3)..)
-        const int tr_off = (8 * q + (r >> 2)) * LSM + 4 * (r & 3);
+        const int tr_off = (8 * q + (r >> 2)) * LSM + 4 * (r & 3), tr_offb = (8 * q + (r >> 2)) * LSN + 4 * (r & 3);
         auto trd = [&](const u16* p) {
             return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) v4s*)(reinterpret_cast<uintptr_t>(p)));
@@ -156,8 +162,8 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                 }
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
-                    const u16* pb = sB + (buf * BK + 32 * s2) * LSM + tr_off + wn * 64 + 16 * n;
-                    const v4s lo = trd(pb), hi = trd(pb + 4 * LSM);
+                    const u16* pb = sB + (buf * BK + 32 * s2) * LSN + tr_offb + wn * 16 * TN + 16 * n;
+                    const v4s lo = trd(pb), hi = trd(pb + 4 * LSN);
                     fb[n] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
@@ -187,34 +193,36 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
         // global -> register -> LDS: 16-B pieces, 8 consecutive lanes = one 128-B line of one row
         const int prow = tid >> 3, pk = (tid & 7) * 8;     // piece (row, k) of pass i: row = prow + 32 i
         const u16* ga[4];
-        const u16* gb[4];
+        const u16* gb[PB];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int ra = m0 + prow + 32 * i, rb = n0 + prow + 32 * i;
+            int ra = m0 + prow + 32 * i;
             ra = ra < M ? ra : M - 1;  // clamped rows only feed outputs the epilogue never stores
-            rb = rb < N ? rb : N - 1;
             ga[i] = A + (size_t)ra * d.lda + pk;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int rb = n0 + prow + 32 * i;
+            rb = rb < N ? rb : N - 1;
             gb[i] = B + (size_t)rb * d.ldb + pk;
         }
-        bf16x8 ra_[2][4], rb_[2][4];  // two k tiles in flight in registers (see the k-major loop above)
+        bf16x8 ra_[2][4], rb_[2][PB];  // two k tiles in flight in registers (see the k-major loop above)
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
         auto gload = [&](auto P, int t) {
             constexpr int p = decltype(P)::value;
             const int k0 = t * BK;
             const bool in = k0 + pk < K;  // K % 32 == 0: the last tile may hold only its first half
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra_[p][i] = in ? ldgb<bf16x8>(ga[i] + k0) : zero8;
-                rb_[p][i] = in ? ldgb<bf16x8>(gb[i] + k0) : zero8;
-            }
+            for (int i = 0; i < 4; ++i) ra_[p][i] = in ? ldgb<bf16x8>(ga[i] + k0) : zero8;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) rb_[p][i] = in ? ldgb<bf16x8>(gb[i] + k0) : zero8;
         };
         auto lstore = [&](auto P, int buf) {
             constexpr int p = decltype(P)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<bf16x8*>(sA + (buf * BM + prow + 32 * i) * LS + pk) = ra_[p][i];
-                *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[p][i];
-            }
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(sA + (buf * BM + prow + 32 * i) * LS + pk) = ra_[p][i];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<bf16x8*>(sB + (buf * BN + prow + 32 * i) * LS + pk) = rb_[p][i];
         };
         // k tiles of this workgroup: all of them, or slice ksg of a cross-workgroup split (weight gradients)
         const int nt_all = (K + BK - 1) / BK;
@@ -240,7 +248,7 @@ __device__ __forceinline__ void gemm_tile_bf16(const GemmDescBf& d, int tm, int 
                     fa[m] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + wm * 64 + 16 * m + r) * LS + 32 * s2 + 8 * q);
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
-                    fb[n] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + wn * 64 + 16 * n + r) * LS + 32 * s2 + 8 * q);
+                    fb[n] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + wn * 16 * TN + 16 * n + r) * LS + 32 * s2 + 8 * q);
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -581,7 +589,8 @@ template <int TM, int TN, int WM, int WN, int KS, int D, bool STAGED, bool CT>
 static hipError_t launch_bf_ct(GemmBatchBf& b, hipStream_t stream) {
     constexpr int BM = WM * 16 * TM, BN = WN * 16 * TN;
     constexpr size_t lds_epi = (size_t)(KS * BM * (BN + 4) + KS * BM + 8 + (CT ? 7 * BN : 0)) * sizeof(float);  // CT: + the table tile
-    constexpr size_t lds_stage = STAGED ? (size_t)2 * (BM + BN) * (64 + 8) * 2 : 0;  // two buffers of A and B panels
+    // two buffers of A and B panels; the k-major image ([64 k][BM + 8] + [64 k][BN + 8]) is never larger than this
+    constexpr size_t lds_stage = STAGED ? (size_t)2 * (BM + BN) * (64 + 8) * 2 : 0;
     constexpr size_t lds = lds_epi > lds_stage ? lds_epi : lds_stage;
     int t = 0;
     for (int i = 0; i < b.n; ++i) {
@@ -635,10 +644,22 @@ hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
     }
     const char* bm = getenv("PSVAE_BF16_BIG_MIN");  // tuning / tests (read per call: a test flips it in-process)
     const int big_min = bm ? atoi(bm) : 2048;
-    if (b.force_staged) return launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream);  // backward of a large batch (see the API)
-    static const int t88_min = getenv("PSVAE_BF16_T88_MIN") ? atoi(getenv("PSVAE_BF16_T88_MIN")) : 256;
-    if (t88_min > 0 && t88 >= t88_min && kmax <= 1024)  // a full machine of 128x128 tiles: half the operand bytes of 64x64
+    if (b.force_staged) {  // the backward launches (see the API)
+        // a launch that gives a 128x128 tiling at most one workgroup per CU runs 128x64 tiles instead: two workgroups
+        // share a CU, so one's store burst and LDS exchange run under the other's k loop
+        long t88s = 0;
+        for (int i = 0; i < b.n; ++i)
+            t88s += (long)((b.d[i].M + 127) / 128) * ((b.d[i].N + 127) / 128) * (b.d[i].ksplit > 1 ? b.d[i].ksplit : 1);
+        static const int half_max = getenv("PSVAE_BF16_HALF_MAX") ? atoi(getenv("PSVAE_BF16_HALF_MAX")) : 256;
+        if (t88s <= half_max) return launch_bf<4, 2, 2, 2, 1, 2, true>(b, stream);
         return launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream);
+    }
+    static const int t88_min = getenv("PSVAE_BF16_T88_MIN") ? atoi(getenv("PSVAE_BF16_T88_MIN")) : 128;
+    if (t88_min > 0 && t88 >= t88_min && kmax <= 1024) {  // a full machine of 128x128 tiles: half the operand bytes of 64x64
+        static const int fwd_half_max = getenv("PSVAE_BF16_FWD_HALF_MAX") ? atoi(getenv("PSVAE_BF16_FWD_HALF_MAX")) : 256;
+        if (t88 <= fwd_half_max) return launch_bf<4, 2, 2, 2, 1, 2, true>(b, stream);  // (two workgroups per CU, as above)
+        return launch_bf<4, 4, 2, 2, 1, 2, true>(b, stream);
+    }
     if (t44 >= 192) {
         const char* st = getenv("PSVAE_BF16_STAGED");
         const int staged = st ? atoi(st) : 1;
