@@ -372,7 +372,7 @@ def bench_langevin(args, rk: Rank):
                          "flop_per_row_step": fpr,
                          "note": "the chain keeps z in registers for all steps (HBM traffic: one read + one write of z per "
                                  "launch); 94 % of its FLOPs are the classifier's 64->128 layer forward and backward, on "
-                                 "fp32 MFMA (one wavefront per 16 rows); the rest is Philox / softmax / update VALU work"}}), flush=True)
+                                 "fp32 MFMA (one wavefront per 16 rows, four per SIMD); the rest is Philox / softmax / update VALU work"}}), flush=True)
 
 
 def committed_traffic(D, Z, B, dtype, plan):

@@ -15,6 +15,8 @@
 //   logits = W2 relu(W1 z + b1) + b2          (latent_classifier.py:30-40; or logits = W1 z + b1 when hidden == 0)
 //   grad   = d/dz [ log_softmax(logits)[target] - 0.5 |z|^2 ]                      (inference.py:56-93)
 //   z     += 0.5 s^2 grad + s w noise                                              (inference.py:97)
+#include <mutex>
+
 #include "psvae_common.h"
 
 namespace psvae {
@@ -332,6 +334,193 @@ __global__ __launch_bounds__(256) void langevin_mfma_kernel(int64_t N, int C, co
     }
 }
 
+// Same chain with the W1 fragments in LDS instead of registers: the register-resident form above fills the register file
+// (one wavefront per SIMD), so a step's Philox / softmax / update VALU work and its MFMAs take turns.  Here each lane's
+// fragments are pre-arranged in LDS as contiguous 16-byte pieces in exactly the order the loop consumes them
+//   forward : Wf[s][q][r][m]   (k step s = 4 m' + j', hidden block m)   -> two ds_read_b128 per k step (HB = 8)
+//   backward: Wb[s2][q][r][m'] (k step s2 = 4 m + j, feature block m')  -> one ds_read_b128 per k step (ZB = 4)
+// (a wavefront reads 64 consecutive pieces: conflict-free), the kernel needs < 128 registers, and 512-thread persistent
+// workgroups put four wavefronts on every SIMD: one wavefront's VALU work runs under the others' MFMAs.
+template <int ZB, int HB>
+__global__ __launch_bounds__(512, 4) void langevin_mfma_lds_kernel(int64_t N, int C, const float* __restrict__ W1,
+                                                                   const float* __restrict__ b1,
+                                                                   const float* __restrict__ W2,
+                                                                   const float* __restrict__ b2, float* __restrict__ zio,
+                                                                   int target, float step_size, float noise_weight,
+                                                                   int64_t num_steps, const float* __restrict__ noises,
+                                                                   uint64_t seed, uint64_t offset,
+                                                                   float* __restrict__ history) {
+    constexpr int ZD = 16 * ZB, HD = 16 * HB;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* sWf = lsm;                       // [4 ZB][4][16][HB]
+    float* sWb = sWf + 4 * ZB * 64 * HB;    // [4 HB][4][16][ZB]
+    float* sW2 = sWb + 4 * HB * 64 * ZB;    // [C][HD]
+    float* sb1 = sW2 + LV_MAXC * HD;        // [HD]
+    float* sb2 = sb1 + HD;                  // [C]
+    for (int i = threadIdx.x; i < 4 * ZB * 64 * HB; i += 512) {
+        const int m = i % HB, rr_ = (i / HB) % 16, qq = (i / (HB * 16)) % 4, s_ = i / (HB * 64);
+        sWf[i] = W1[(size_t)(16 * m + rr_) * ZD + 16 * (s_ >> 2) + 4 * qq + (s_ & 3)];
+    }
+    for (int i = threadIdx.x; i < 4 * HB * 64 * ZB; i += 512) {
+        const int mp = i % ZB, rr_ = (i / ZB) % 16, qq = (i / (ZB * 16)) % 4, s2 = i / (ZB * 64);
+        sWb[i] = W1[(size_t)(16 * (s2 >> 2) + 4 * qq + (s2 & 3)) * ZD + 16 * mp + rr_];
+    }
+    for (int i = threadIdx.x; i < C * HD; i += 512) sW2[i] = W2[i];
+    for (int i = threadIdx.x; i < HD; i += 512) sb1[i] = b1[i];
+    if (threadIdx.x < C) sb2[threadIdx.x] = b2[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const float drift = 0.5f * step_size * step_size, nsc = step_size * noise_weight;
+    const uint64_t blocks_per_step = (uint64_t)((N * ZD + 3) / 4);
+    const int64_t ngroups = (N + 15) / 16;
+    const float* __restrict__ myWf = sWf + (q * 16 + r) * HB;
+    const float* __restrict__ myWb = sWb + (q * 16 + r) * ZB;
+    for (int64_t g = (int64_t)blockIdx.x * 8 + wave; g < ngroups; g += (int64_t)gridDim.x * 8) {
+        const int64_t row = g * 16 + r;
+        const bool live = row < N;
+        const int64_t rr = live ? row : N - 1;
+        float z[4 * ZB];
+#pragma unroll
+        for (int mp = 0; mp < ZB; ++mp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(zio + rr * ZD + 16 * mp + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[4 * mp + j] = v[j];
+        }
+        for (int64_t t = 0; t < num_steps; ++t) {
+            f32x4 h[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h[m] = *reinterpret_cast<const f32x4*>(sb1 + 16 * m + 4 * q);
+            {   // one k step of fragments ahead of the MFMAs; the sched_barriers keep the compiler from hoisting ALL
+                // fragment reads to the top (it did: 768 B of scratch per lane at the 128-register budget)
+                f32x4 wn[HB / 4];
+#pragma unroll
+                for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + 4 * m4);
+#pragma unroll
+                for (int s = 0; s < 4 * ZB; ++s) {
+                    f32x4 w[HB / 4];
+#pragma unroll
+                    for (int m4 = 0; m4 < HB / 4; ++m4) w[m4] = wn[m4];
+                    if (s + 1 < 4 * ZB) {
+#pragma unroll
+                        for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + (s + 1) * 64 * HB + 4 * m4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[m >> 2][m & 3], z[s], h[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            float logits[LV_MAXC];
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c) logits[c] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[m][j] = fmaxf(h[m][j], 0.f);
+#pragma unroll
+                for (int c = 0; c < LV_MAXC; ++c)
+                    if (c < C) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + c * HD + 16 * m + 4 * q);
+                        logits[c] = fmaf(w[0], h[m][0], fmaf(w[1], h[m][1], fmaf(w[2], h[m][2], fmaf(w[3], h[m][3], logits[c]))));
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c)
+                if (c < C) {
+                    logits[c] += __shfl_xor(logits[c], 16);
+                    logits[c] += __shfl_xor(logits[c], 32);
+                    logits[c] += sb2[c];
+                }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c)
+                if (c < C) mx = fmaxf(mx, logits[c]);
+            float den = 0.f, gl[LV_MAXC];
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c) {
+                gl[c] = c < C ? expf(logits[c] - mx) : 0.f;
+                den += gl[c];
+            }
+#pragma unroll
+            for (int c = 0; c < LV_MAXC; ++c) gl[c] = (c == target ? 1.f : 0.f) - gl[c] / den;
+            if (C == 1) gl[0] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < LV_MAXC; ++c)
+                    if (c < C) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(sW2 + c * HD + 16 * m + 4 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gacc[j] = fmaf(w[j], gl[c], gacc[j]);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[m][j] = h[m][j] > 0.f ? gacc[j] : 0.f;
+            }
+            f32x4 gz[ZB];
+#pragma unroll
+            for (int mp = 0; mp < ZB; ++mp) gz[mp] = f32x4{-z[4 * mp], -z[4 * mp + 1], -z[4 * mp + 2], -z[4 * mp + 3]};
+            {
+                f32x4 wn[ZB / 4];
+#pragma unroll
+                for (int m4 = 0; m4 < ZB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWb + 4 * m4);
+#pragma unroll
+                for (int s2 = 0; s2 < 4 * HB; ++s2) {
+                    f32x4 w[ZB / 4];
+#pragma unroll
+                    for (int m4 = 0; m4 < ZB / 4; ++m4) w[m4] = wn[m4];
+                    if (s2 + 1 < 4 * HB) {
+#pragma unroll
+                        for (int m4 = 0; m4 < ZB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWb + (s2 + 1) * 64 * ZB + 4 * m4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mp = 0; mp < ZB; ++mp)
+                        gz[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mp >> 2][mp & 3], h[s2 >> 2][s2 & 3], gz[mp], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int mp = 0; mp < ZB; ++mp) {
+                // this step's noise: generated here, at its use (the other wavefronts of the SIMD issue MFMAs meanwhile)
+                const f32x4 nzv = noises ? *reinterpret_cast<const f32x4*>(noises + ((size_t)t * N + rr) * ZD + 16 * mp + 4 * q)
+                                         : normal4(offset + (uint64_t)t * blocks_per_step + (uint64_t)((rr * ZD + 16 * mp + 4 * q) >> 2), seed);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[4 * mp + j] += drift * gz[mp][j] + nsc * nzv[j];
+                if (history && live)
+                    *reinterpret_cast<f32x4*>(history + ((size_t)t * N + row) * ZD + 16 * mp + 4 * q) =
+                        f32x4{z[4 * mp], z[4 * mp + 1], z[4 * mp + 2], z[4 * mp + 3]};
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int mp = 0; mp < ZB; ++mp)
+                *reinterpret_cast<f32x4*>(zio + row * ZD + 16 * mp + 4 * q) = f32x4{z[4 * mp], z[4 * mp + 1], z[4 * mp + 2], z[4 * mp + 3]};
+        }
+    }
+}
+
+template <int ZB, int HB>
+static hipError_t launch_langevin_mfma_lds(int64_t N, int C, const float* W1, const float* b1, const float* W2,
+                                           const float* b2, float* z, int target, float step_size, float noise_weight,
+                                           int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
+                                           float* history, hipStream_t s) {
+    constexpr size_t lds = (size_t)(2 * 4 * ZB * 64 * HB + LV_MAXC * 16 * HB + 16 * HB + LV_MAXC) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&langevin_mfma_lds_kernel<ZB, HB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    const int64_t groups = (N + 15) / 16, wgs = (groups + 7) / 8;
+    const int per_cu = (int)((160 * 1024) / lds) >= 2 ? 2 : 1;
+    const int grid = (int)(wgs < 256 * per_cu ? wgs : 256 * per_cu);  // persistent: every workgroup walks its row groups
+    hipLaunchKernelGGL((langevin_mfma_lds_kernel<ZB, HB>), dim3(grid), dim3(512), lds, s, N, C, W1, b1, W2, b2, z, target,
+                       step_size, noise_weight, num_steps, noises, seed, offset, history);
+    return hipGetLastError();
+}
+
 template <int ZB, int HB>
 static hipError_t launch_langevin_mfma(int64_t N, int C, const float* W1, const float* b1, const float* W2, const float* b2,
                                        float* z, int target, float step_size, float noise_weight, int64_t num_steps,
@@ -348,6 +537,15 @@ hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1,
                            hipStream_t s) {
     // heads whose two sizes are whole 16-blocks and whose W1 fragments fit the register file run on the matrix cores
     static const bool mfma_on = getenv("PSVAE_LANGEVIN_VALU") == nullptr;
+    static const bool lds_form = getenv("PSVAE_LANGEVIN_REGS") == nullptr;  // (0: W1 fragments in registers, 1 wave per SIMD)
+    if (mfma_on && lds_form && hidden > 0 && (reinterpret_cast<uintptr_t>(W1) & 15) == 0) {
+#define PSVAE_LVL(ZB, HB)                                                                                               \
+    if (Z == 16 * ZB && hidden == 16 * HB)                                                                              \
+        return launch_langevin_mfma_lds<ZB, HB>(N, C, W1, b1, W2, b2, z, target, step_size, noise_weight, num_steps,    \
+                                                noises, seed, offset, history, s);
+        PSVAE_LVL(4, 8) PSVAE_LVL(4, 4) PSVAE_LVL(8, 4) PSVAE_LVL(8, 8)
+#undef PSVAE_LVL
+    }
     if (mfma_on && hidden > 0 && (reinterpret_cast<uintptr_t>(W1) & 15) == 0) {
 #define PSVAE_LVM(ZB, HB)                                                                                           \
     if (Z == 16 * ZB && hidden == 16 * HB)                                                                          \
