@@ -1,0 +1,230 @@
+// Fused decode (VAEModel.decode, /root/reference/ps_vae/model.py:65-69; the sampling path of inference.py:25,105 --
+// BASELINE config 5): all three decoder layers in ONE kernel, hidden activations never leave the register file.
+//
+// The per-layer path (psvae_api.hip: three grouped-GEMM launches per 65,536-row chunk) writes d1 and d2 -- 2 KB per row
+// each -- to memory and reads them back: 8 GB per 1 M rows, and each launch runs at the tile kernel's 66 % of the fp32
+// MFMA peak.  Here one wavefront owns 16 rows for all three layers, everything TRANSPOSED (as in langevin.hip):
+//     d^T [out x 16 rows] = W [out x in] . a^T [in x 16 rows]         A = weight fragments, B = activations, C init = bias
+// v_mfma_f32_16x16x4_f32: lane (r, q) supplies A[i = r][k = q], B[k = q][n = r] and receives D[i = 4q + j][n = r]: a
+// layer's output (lane (r, q): features 16 m + 4q + j of row r) is, register for register, the next layer's B operand,
+// with k slot q of MFMA step (mb, j) = feature 16 mb + 4q + j.  The weights are PRE-PACKED once per call in exactly
+// that consumption order -- Wp[layer][mb][j][m/4][q][r][m%4] = W[16 m + r][16 mb + 4q + j] -- so the four wavefronts of a
+// workgroup stream them global -> registers -> LDS as plain 16-byte copies (32 KB chunks, three LDS buffers, one
+// barrier per chunk of 128 MFMAs per wavefront) and read their fragments as contiguous ds_read_b128.
+// Per 16 rows: 6,656 MFMAs (Z = 64, D = 256) against 96 KB of LDS fragment reads per wavefront -- MFMA-bound.
+#include <mutex>
+#include <type_traits>
+
+#include "psvae_common.h"
+
+namespace psvae {
+
+// ---- weight packing: Wp[mb][j][m4][q][r][e] = W[16 (4 m4 + e) + r][16 mb + 4 q + j],  W is [OUT, IN] row-major --------
+// (lane (r, q) reads output blocks 4 m4 .. 4 m4 + 3 of step (mb, j) as ONE 16-byte piece, and the 64 lanes' pieces are
+//  contiguous: a ds_read_b128 of the wavefront covers 1 KB without a bank conflict.  With the m index innermost per
+//  lane -- a 128-byte lane stride -- the 16 r lanes would all fall on the same four banks.)
+__global__ __launch_bounds__(256) void pack_decode_weights_kernel(const float* __restrict__ W, float* __restrict__ Wp,
+                                                                  int OUT, int IN) {
+    const int M4 = OUT / 64;
+    const long n = (long)OUT * IN;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int e = (int)(i & 3), r = (int)((i >> 2) & 15), q = (int)((i >> 6) & 3);
+        long t = i >> 8;
+        const int m4 = (int)(t % M4); t /= M4;
+        const int j = (int)(t & 3);
+        const int mb = (int)(t >> 2);
+        Wp[i] = W[(size_t)(16 * (4 * m4 + e) + r) * IN + 16 * mb + 4 * q + j];
+    }
+}
+
+constexpr int DF_MAXP = 8;  // pieces per thread of the largest chunk (MBO = 32: 32 KB)
+
+struct DecodeFusedArgs {
+    const float* z;       // [N, Z]
+    float* x_hat;         // [N, D]
+    const float* wp;      // packed weights: layer 0 | layer 1 | layer 2
+    const float* bias0;   // [512]
+    const float* bias1;   // [512]
+    const float* bias2;   // [D]
+    long N;
+    int Z, D;
+};
+
+template <int ZB, int DB>  // Z = 16 ZB, D = 16 DB, hidden = 512
+__global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedArgs a) {
+    constexpr int HB = H / 16;                      // 32 hidden blocks
+    constexpr int CH_H = 4 * 4 * 16 * HB;           // floats per chunk of a layer with 512 outputs (32 KB)
+    constexpr int CH_D = 4 * 4 * 16 * DB;           // ... of the output layer
+    constexpr int NCH = ZB + HB + HB;               // chunks of the whole weight stream per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wbuf = lds;                              // [3][CH_H]: chunk c lives in buffer c % 3
+    float* sbias = lds + 3 * CH_H;                  // [512 + 512 + D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    for (int i = tid; i < H; i += 256) { sbias[i] = a.bias0[i]; sbias[H + i] = a.bias1[i]; }
+    for (int i = tid; i < 16 * DB; i += 256) sbias[2 * H + i] = a.bias2[i];
+
+    // chunk c of the stream.  The loops below are fully unrolled (the activations are indexed statically), so every
+    // chunk's address would be a loop invariant the compiler precomputes -- 68 address pairs, spilled.  One running
+    // pointer, opaque to the optimiser, is advanced per fetch instead.
+    auto ch_len = [&](int c) -> int { return c < ZB + HB ? CH_H : CH_D; };
+    auto ch_mbo = [&](int c) -> int { return c < ZB + HB ? HB : DB; };
+    f32x4 pf[DF_MAXP];  // the next chunk, in flight
+    // (explicitly global: behind the asm the compiler would fall back to flat loads, which count on lgkmcnt too and
+    //  force every LDS wait to lgkmcnt(0) -- the fragment lookahead would be lost)
+    typedef const __attribute__((address_space(1))) float gfloat;
+    typedef const __attribute__((address_space(1))) f32x4 gf32x4;
+    gfloat* wsrc = nullptr;
+    auto gfetch = [&](int c) {
+        if (c == 0) wsrc = (gfloat*)(a.wp + 4 * tid);
+        asm volatile("" : "+v"(wsrc));
+        const int np = ch_len(c) / 4 / 256;
+#pragma unroll
+        for (int i = 0; i < DF_MAXP; ++i)
+            if (i < np) pf[i] = *(const gf32x4*)(wsrc + 1024 * i);
+        wsrc += ch_len(c);
+    };
+    auto lstore = [&](int c) {
+        float* dst = wbuf + (c % 3) * CH_H;
+        const int np = ch_len(c) / 4 / 256;
+#pragma unroll
+        for (int i = 0; i < DF_MAXP; ++i)
+            if (i < np) *reinterpret_cast<f32x4*>(dst + 4 * (tid + 256 * i)) = pf[i];
+    };
+    // this lane's fragments of step j of chunk c: piece m4 at [j][m4][q][r][0..3]
+    f32x4 w[2][HB / 4];  // two sets: the step being multiplied and the one after it
+    auto frag = [&](int set, int c, int j) {
+        const int mbo = ch_mbo(c);
+        const float* wl = wbuf + (c % 3) * CH_H + j * (mbo / 4) * 256 + lane * 4;
+#pragma unroll
+        for (int m4 = 0; m4 < HB / 4; ++m4)
+            if (m4 < mbo / 4) w[set][m4] = *reinterpret_cast<const f32x4*>(wl + 256 * m4);
+    };
+
+    const long ntiles = (a.N + 63) / 64;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row = tile * 64 + wave * 16 + r;
+        const bool live = row < a.N;
+        const long rr = live ? row : a.N - 1;
+        // stream start: chunk 0 into buffer 0, chunk 1 in flight.  (The barrier also separates the previous tile's last
+        // reads from this tile's first writes and publishes sbias.)
+        gfetch(0);
+        __syncthreads();
+        lstore(0);
+        gfetch(1);
+        __syncthreads();
+        frag(0, 0, 0);
+        int c = 0;  // current chunk of the stream
+
+        // one chunk = 4 MFMA steps (input features 16 mb + 4q + j, j = 0..3) over MBO output blocks.
+        //   step j:   request the NEXT step's fragments (next chunk's step 0 after j = 3: made visible by this chunk's
+        //             barrier), multiply with the current set;
+        //   after 0:  the chunk in flight goes to buffer (c + 1) % 3 -- last read during chunk c - 2, which every
+        //             wavefront finished before the barrier of chunk c - 1 -- and chunk c + 2 is requested;
+        //   after 1:  the one barrier of the chunk.
+        auto chunk = [&](auto MBOc, f32x4* acc, auto bsel) {
+            constexpr int MBO = decltype(MBOc)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < 3) frag((j + 1) & 1, c, j + 1);
+                else if (c + 1 < NCH) frag(0, c + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const float b = bsel(j);
+#pragma unroll
+                for (int m = 0; m < MBO; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j & 1][m >> 2][m & 3], b, acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+                    if (c + 1 < NCH) lstore(c + 1);
+                    if (c + 2 < NCH) gfetch(c + 2);
+                }
+                if (j == 1) __syncthreads();
+            }
+            ++c;
+        };
+
+        float zin[4 * ZB];
+#pragma unroll
+        for (int mb = 0; mb < ZB; ++mb) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.z + rr * a.Z + 16 * mb + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zin[4 * mb + j] = v[j];
+        }
+        f32x4 d1[HB], d2[HB];
+        // ---- layer 0: Z -> 512, ReLU ----
+#pragma unroll
+        for (int m = 0; m < HB; ++m) d1[m] = *reinterpret_cast<const f32x4*>(sbias + 16 * m + 4 * q);
+#pragma unroll
+        for (int mb = 0; mb < ZB; ++mb)
+            chunk(std::integral_constant<int, HB>{}, d1, [&](int j) { return zin[4 * mb + j]; });
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d1[m][j] = fmaxf(d1[m][j], 0.f);
+        // ---- layer 1: 512 -> 512, ReLU ----
+#pragma unroll
+        for (int m = 0; m < HB; ++m) d2[m] = *reinterpret_cast<const f32x4*>(sbias + H + 16 * m + 4 * q);
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+            chunk(std::integral_constant<int, HB>{}, d2, [&](int j) { return d1[mb][j]; });
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d2[m][j] = fmaxf(d2[m][j], 0.f);
+        // ---- layer 2: 512 -> D, no activation; the accumulators reuse d1's registers ----
+        f32x4* out = d1;
+#pragma unroll
+        for (int m = 0; m < DB; ++m) out[m] = *reinterpret_cast<const f32x4*>(sbias + 2 * H + 16 * m + 4 * q);
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+            chunk(std::integral_constant<int, DB>{}, out, [&](int j) { return d2[mb][j]; });
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < DB; ++m) *reinterpret_cast<f32x4*>(a.x_hat + row * a.D + 16 * m + 4 * q) = out[m];
+        }
+    }
+}
+
+size_t decode_fused_pack_floats(int Z, int D) { return (size_t)H * Z + (size_t)H * H + (size_t)D * H; }
+
+bool decode_fused_ok(int64_t N, int Z, int D) {
+    // (read per call: the parity tests run both paths in one process)
+    const bool off = getenv("PSVAE_DECODE_UNFUSED") != nullptr;
+    const long minrows = getenv("PSVAE_DECODE_FUSED_MIN") ? atol(getenv("PSVAE_DECODE_FUSED_MIN")) : 16384;
+    return !off && N >= minrows && (Z == 64 || Z == 32 || Z == 128) && (D == 256 || D == 512 || D == 128);
+}
+
+template <int ZB, int DB>
+static hipError_t launch_decode_fused_t(const DecodeFusedArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)(3 * 4 * 4 * 16 * (H / 16) + 2 * H + 16 * DB) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_fused_kernel<ZB, DB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    const long ntiles = (a.N + 63) / 64;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // persistent: one workgroup per CU walks the row tiles
+    hipLaunchKernelGGL((decode_fused_kernel<ZB, DB>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// pack the three weight matrices into `wp` (decode_fused_pack_floats floats) and run the fused kernel
+hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat, float* wp,
+                               hipStream_t s) {
+    float* wp0 = wp;
+    float* wp1 = wp0 + (size_t)H * Z;
+    float* wp2 = wp1 + (size_t)H * H;
+    hipLaunchKernelGGL(pack_decode_weights_kernel, dim3(128), dim3(256), 0, s, dec6[0], wp0, H, Z);
+    hipLaunchKernelGGL(pack_decode_weights_kernel, dim3(256), dim3(256), 0, s, dec6[2], wp1, H, H);
+    hipLaunchKernelGGL(pack_decode_weights_kernel, dim3(256), dim3(256), 0, s, dec6[4], wp2, D, H);
+    DecodeFusedArgs a{};
+    a.z = z; a.x_hat = x_hat; a.wp = wp; a.bias0 = dec6[1]; a.bias1 = dec6[3]; a.bias2 = dec6[5];
+    a.N = N; a.Z = Z; a.D = D;
+#define PSVAE_DF(ZB, DB) if (Z == 16 * ZB && D == 16 * DB) return launch_decode_fused_t<ZB, DB>(a, s)
+    PSVAE_DF(4, 16); PSVAE_DF(8, 32); PSVAE_DF(2, 16); PSVAE_DF(4, 8); PSVAE_DF(4, 32); PSVAE_DF(8, 16);
+#undef PSVAE_DF
+    return hipErrorInvalidValue;
+}
+
+}  // namespace psvae

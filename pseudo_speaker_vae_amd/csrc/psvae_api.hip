@@ -925,6 +925,17 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
     float* d1 = reinterpret_cast<float*>(scratch);
     float* d2 = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + align_up((size_t)c * H * sizeof(float), 256));
     float* yn = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 2 * align_up((size_t)c * H * sizeof(float), 256));
+    if (!cond_tab && decode_fused_ok(N, (int)Z, (int)D) &&
+        decode_fused_pack_floats((int)Z, (int)D) * sizeof(float) <= 2 * align_up((size_t)c * H * sizeof(float), 256)) {
+        // all three layers in one kernel (decode_fused.hip); the packed weights take the place of d1 / d2
+        RET_IF(launch_decode_fused(N, (int)Z, (int)D, z, dec6, x_hat, d1, s));
+        if (normalize)
+            for (int64_t r0 = 0; r0 < N; r0 += c) {
+                const int n = (int)((N - r0) < c ? (N - r0) : c);
+                RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+            }
+        return 0;
+    }
     for (int64_t r0 = 0; r0 < N; r0 += c) {
         const int n = (int)((N - r0) < c ? (N - r0) : c);
         {

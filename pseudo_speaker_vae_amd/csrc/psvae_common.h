@@ -277,4 +277,10 @@ hipError_t launch_gather_rows(const float* table, int64_t N, int D, const int64_
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                        double b1, double b2, double eps, double wd, double gscale, hipStream_t s);
 
+// decode_fused.hip: the three decoder layers in one kernel (hidden activations stay in registers)
+bool decode_fused_ok(int64_t N, int Z, int D);
+size_t decode_fused_pack_floats(int Z, int D);
+hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat, float* wp,
+                               hipStream_t s);
+
 }  // namespace psvae
