@@ -211,6 +211,10 @@ int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const flo
 int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6,
                      const float* cond_tab /* nullable [6,512] */, const int32_t* gender,
                      const int32_t* age, float* x_hat, void* scratch, uint32_t flags, void* stream);
+/* kernel launches the calling thread's most recent psvae_decode_f32 issued: the fused decode (all three
+ * layers in one kernel; N >= 16384, no conditional table, Z in {32,64,128}, D in {128,256,512}) issues 4 (three weight
+ * packs + the kernel) plus the normalisation launches, the per-layer path 3 per 65,536-row chunk */
+int psvae_last_decode_launches(void);
 
 /* Test / bench hook: one fp32 MFMA GEMM of the kind the path is built from.
  *   kind 0 (NT): C[M,N] = A[M,K] B[N,K]^T     (forward Linear, model.py:15)

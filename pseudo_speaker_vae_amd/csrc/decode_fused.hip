@@ -83,60 +83,84 @@ __global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedA
             if (i < np) pf[i] = *(const gf32x4*)(wsrc + 1024 * i);
         wsrc += ch_len(c);
     };
-    auto lstore = [&](int c) {
-        float* dst = wbuf + (c % 3) * CH_H;
-        const int np = ch_len(c) / 4 / 256;
+    // the stream is CYCLIC: chunk u (counted from the first tile on) lives in buffer u % 3 and NCH % 3 != 0, so a tile's
+    // chunk c sits at base[c % 3] with the three bases rotated per tile -- the last chunks of a tile already stage and
+    // read the first chunks of the next one, no restart at a tile boundary.
+    int base[3] = {0, CH_H, 2 * CH_H};
+    auto lstore = [&](int u) {  // u may run past NCH (next tile's chunks)
+        float* dst = wbuf + base[u % 3];
+        const int np = ch_len(u % NCH) / 4 / 256;
 #pragma unroll
         for (int i = 0; i < DF_MAXP; ++i)
             if (i < np) *reinterpret_cast<f32x4*>(dst + 4 * (tid + 256 * i)) = pf[i];
     };
-    // this lane's fragments of step j of chunk c: piece m4 at [j][m4][q][r][0..3]
+    // this lane's fragments of step j of chunk u: piece m4 at [j][m4][q][r][0..3]
     f32x4 w[2][HB / 4];  // two sets: the step being multiplied and the one after it
-    auto frag = [&](int set, int c, int j) {
-        const int mbo = ch_mbo(c);
-        const float* wl = wbuf + (c % 3) * CH_H + j * (mbo / 4) * 256 + lane * 4;
+    auto frag = [&](int set, int u, int j) {
+        const int mbo = ch_mbo(u % NCH);
+        const float* wl = wbuf + base[u % 3] + j * (mbo / 4) * 256 + lane * 4;
 #pragma unroll
         for (int m4 = 0; m4 < HB / 4; ++m4)
             if (m4 < mbo / 4) w[set][m4] = *reinterpret_cast<const f32x4*>(wl + 256 * m4);
     };
 
     const long ntiles = (a.N + 63) / 64;
+    auto zrow = [&](long tile) -> long {
+        const long row = tile * 64 + wave * 16 + r;
+        return row < a.N ? row : a.N - 1;
+    };
+    f32x4 znext[ZB];  // the next tile's latent rows, requested a layer ahead
+    auto zfetch = [&](long tile) {
+        const float* zp = a.z + zrow(tile) * a.Z + 4 * q;
+#pragma unroll
+        for (int mb = 0; mb < ZB; ++mb) znext[mb] = *reinterpret_cast<const f32x4*>(zp + 16 * mb);
+    };
+    // stream start (first tile only): chunk 0 into its buffer, chunk 1 in flight
+    gfetch(0);
+    zfetch(blockIdx.x);
+    __syncthreads();  // (publishes sbias)
+    lstore(0);
+    gfetch(1);
+    __syncthreads();
+    frag(0, 0, 0);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row = tile * 64 + wave * 16 + r;
         const bool live = row < a.N;
-        const long rr = live ? row : a.N - 1;
-        // stream start: chunk 0 into buffer 0, chunk 1 in flight.  (The barrier also separates the previous tile's last
-        // reads from this tile's first writes and publishes sbias.)
-        gfetch(0);
-        __syncthreads();
-        lstore(0);
-        gfetch(1);
-        __syncthreads();
-        frag(0, 0, 0);
         int c = 0;  // current chunk of the stream
 
         // one chunk = 4 MFMA steps (input features 16 mb + 4q + j, j = 0..3) over MBO output blocks.
         //   step j:   request the NEXT step's fragments (next chunk's step 0 after j = 3: made visible by this chunk's
         //             barrier), multiply with the current set;
-        //   after 0:  the chunk in flight goes to buffer (c + 1) % 3 -- last read during chunk c - 2, which every
-        //             wavefront finished before the barrier of chunk c - 1 -- and chunk c + 2 is requested;
+        //   step 0:   between its MFMAs the chunk in flight goes to the buffer of chunk c + 1 -- last read during chunk
+        //             c - 2, which every wavefront finished before the barrier of chunk c - 1 -- and chunk c + 2 is
+        //             requested;
         //   after 1:  the one barrier of the chunk.
         auto chunk = [&](auto MBOc, f32x4* acc, auto bsel) {
             constexpr int MBO = decltype(MBOc)::value;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < 3) frag((j + 1) & 1, c, j + 1);
-                else if (c + 1 < NCH) frag(0, c + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                else frag(0, c + 1, 0);
+                if (j != 0) __builtin_amdgcn_sched_barrier(0);
                 const float b = bsel(j);
 #pragma unroll
                 for (int m = 0; m < MBO; ++m)
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j & 1][m >> 2][m & 3], b, acc[m], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
                 if (j == 0) {
-                    if (c + 1 < NCH) lstore(c + 1);
-                    if (c + 2 < NCH) gfetch(c + 2);
+                    lstore(c + 1);
+                    gfetch((c + 2) % NCH);
+                    // issue order of this step: the fragment reads, then groups of {4 MFMA, 1 LDS write, address arithmetic, 1 global load}
+                    constexpr int NP = MBO / 4;  // 16-byte pieces per thread of a chunk of this layer
+                    __builtin_amdgcn_sched_group_barrier(0x100, MBO / 4, 0);
+#pragma unroll
+                    for (int g = 0; g < NP; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MBO / NP, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 if (j == 1) __syncthreads();
             }
             ++c;
@@ -144,11 +168,9 @@ __global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedA
 
         float zin[4 * ZB];
 #pragma unroll
-        for (int mb = 0; mb < ZB; ++mb) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(a.z + rr * a.Z + 16 * mb + 4 * q);
+        for (int mb = 0; mb < ZB; ++mb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) zin[4 * mb + j] = v[j];
-        }
+            for (int j = 0; j < 4; ++j) zin[4 * mb + j] = znext[mb][j];
         f32x4 d1[HB], d2[HB];
         // ---- layer 0: Z -> 512, ReLU ----
 #pragma unroll
@@ -171,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedA
 #pragma unroll
             for (int j = 0; j < 4; ++j) d2[m][j] = fmaxf(d2[m][j], 0.f);
         // ---- layer 2: 512 -> D, no activation; the accumulators reuse d1's registers ----
+        zfetch(tile + gridDim.x);
         f32x4* out = d1;
 #pragma unroll
         for (int m = 0; m < DB; ++m) out[m] = *reinterpret_cast<const f32x4*>(sbias + 2 * H + 16 * m + 4 * q);
@@ -181,6 +204,8 @@ __global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedA
 #pragma unroll
             for (int m = 0; m < DB; ++m) *reinterpret_cast<f32x4*>(a.x_hat + row * a.D + 16 * m + 4 * q) = out[m];
         }
+        const int b0 = base[NCH % 3], b1 = base[(NCH + 1) % 3], b2 = base[(NCH + 2) % 3];
+        base[0] = b0; base[1] = b1; base[2] = b2;
     }
 }
 
@@ -223,6 +248,7 @@ hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const fl
     a.N = N; a.Z = Z; a.D = D;
 #define PSVAE_DF(ZB, DB) if (Z == 16 * ZB && D == 16 * DB) return launch_decode_fused_t<ZB, DB>(a, s)
     PSVAE_DF(4, 16); PSVAE_DF(8, 32); PSVAE_DF(2, 16); PSVAE_DF(4, 8); PSVAE_DF(4, 32); PSVAE_DF(8, 16);
+    PSVAE_DF(2, 8); PSVAE_DF(2, 32); PSVAE_DF(8, 8);
 #undef PSVAE_DF
     return hipErrorInvalidValue;
 }

@@ -905,6 +905,8 @@ static int64_t decode_chunk() {
 }
 #define DECODE_CHUNK decode_chunk()
 
+static thread_local int t_decode_launches = 0;
+
 size_t psvae_decode_scratch_bytes(int64_t N) {
     if (N <= 0) return 0;
     const int64_t c = N < DECODE_CHUNK ? N : DECODE_CHUNK;
@@ -920,6 +922,7 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
         if (!dec6[i]) return PSVAE_ERR_NULL;
     if (cond_tab && (!gender || !age)) return PSVAE_ERR_NULL;
     hipStream_t s = (hipStream_t)stream;
+    t_decode_launches = 0;
     const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
     const int64_t c = N < DECODE_CHUNK ? N : DECODE_CHUNK;
     float* d1 = reinterpret_cast<float*>(scratch);
@@ -929,10 +932,11 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
         decode_fused_pack_floats((int)Z, (int)D) * sizeof(float) <= 2 * align_up((size_t)c * H * sizeof(float), 256)) {
         // all three layers in one kernel (decode_fused.hip); the packed weights take the place of d1 / d2
         RET_IF(launch_decode_fused(N, (int)Z, (int)D, z, dec6, x_hat, d1, s));
+        t_decode_launches += 4;
         if (normalize)
             for (int64_t r0 = 0; r0 < N; r0 += c) {
                 const int n = (int)((N - r0) < c ? (N - r0) : c);
-                RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+                { RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s)); ++t_decode_launches; }
             }
         return 0;
     }
@@ -944,22 +948,27 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
             if (cond_tab) { d.ctab = cond_tab; d.gender = gender + r0; d.age = age + r0; }
             add(b, d);
             RET_IF(launch_gemm_batch(b, 0, s));
+            ++t_decode_launches;
         }
         {
             GemmBatch b{};
             add(b, make_desc(GK_NT, n, H, H, d1, H, dec6[2], H, d2, H, EPI_BIAS_RELU, dec6[3]));
             RET_IF(launch_gemm_batch(b, 0, s));
+            ++t_decode_launches;
         }
         {
             GemmBatch b{};
             // with normalisation the un-normalised rows go to x_hat first and are normalised in place
             add(b, make_desc(GK_NT, n, (int)D, H, d2, H, dec6[4], H, x_hat + r0 * D, (int)D, EPI_BIAS, dec6[5]));
             RET_IF(launch_gemm_batch(b, 0, s));
+            ++t_decode_launches;
         }
-        if (normalize) RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+        if (normalize) { RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s)); ++t_decode_launches; }
     }
     return 0;
 }
+
+int psvae_last_decode_launches(void) { return t_decode_launches; }
 
 int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const float* W1, const float* b1,
                        const float* W2, const float* b2, float* z, int32_t target, float step_size, float noise_weight,

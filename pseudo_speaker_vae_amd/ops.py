@@ -280,6 +280,11 @@ def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: i
     return xh
 
 
+def last_decode_launches() -> int:
+    """launches of this thread's most recent decode call (4 + normalisation = the fused three-layer kernel ran)"""
+    return int(_ffi.lib().psvae_last_decode_launches())
+
+
 def forward_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], eps: Optional[torch.Tensor] = None, seed: int = 0,
                  offset: int = 0, rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
                  cond=None):

@@ -1,0 +1,106 @@
+"""The fused decode (csrc/decode_fused.hip: VAEModel.decode, /root/reference/ps_vae/model.py:65-69, all three layers in
+one kernel for N >= 16,384 rows) against the oracle and against the per-layer path it replaces.  The oracle decodes
+slices (it is a CPU loop over 1,024 output columns per row); the per-layer HIP path -- itself oracle-checked in
+test_gpu_parity.py / test_gpu_api.py -- is the all-rows checker."""
+import os
+
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import psvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _decode(ops, z, dec, D, fused, **kw):
+    if fused:
+        os.environ.pop("PSVAE_DECODE_UNFUSED", None)
+    else:
+        os.environ["PSVAE_DECODE_UNFUSED"] = "1"
+    try:
+        out = ops.decode(z, dec, D, **kw)
+        torch.cuda.synchronize()
+        return out, ops.last_decode_launches()
+    finally:
+        os.environ.pop("PSVAE_DECODE_UNFUSED", None)
+
+
+@pytest.mark.parametrize("D,Z,N", [(256, 64, 16384), (256, 64, 16384 + 37), (512, 128, 20001), (128, 32, 16400),
+                                   (512, 32, 16385), (128, 128, 17000), (256, 32, 30000), (256, 128, 16447),
+                                   (512, 64, 16391), (128, 64, 65536 + 1)])
+def test_fused_decode_matches_oracle_and_per_layer_path(D, Z, N):
+    from pseudo_speaker_vae_amd import ops
+    p = O.init_params(D, Z, N % 7)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(N * Z, 3, 0, DEV).reshape(N, Z)
+    out = torch.full((N + 1, D), float("nan"), device=DEV)  # one guard row behind the output
+    fused, nf = _decode(ops, z, dec, D, True, out=out[:N])
+    assert nf == 4, "the fused kernel did not run"
+    assert torch.isnan(out[N]).all(), "wrote past the last row"
+    assert torch.isfinite(fused).all()
+    per_layer, npl = _decode(ops, z, dec, D, False)
+    assert npl == 3 * ((N + 65535) // 65536)
+    assert_close(fused.cpu(), per_layer.cpu(), 2e-6, "fused vs per-layer, all rows")
+    for lo, hi in ((0, 70), (N // 2 - 5, N // 2 + 60), (N - 45, N)):  # incl. the ragged last tile
+        ref = O.decode(p, z[lo:hi].cpu())
+        assert_close(fused[lo:hi].cpu(), ref, 1e-4, f"rows {lo}:{hi} vs oracle")
+
+
+def test_fused_decode_with_normalised_output():
+    """normalize_decoder_output (model.py:38,69): rows scaled to unit L2 norm after the fused kernel"""
+    from pseudo_speaker_vae_amd import ops
+    from pseudo_speaker_vae_amd._ffi import NORMALIZE_DECODER as PSVAE_NORMALIZE_DECODER
+    D, Z, N = 256, 64, 70001  # two normalisation chunks
+    p = O.init_params(D, Z, 1)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(N * Z, 8, 0, DEV).reshape(N, Z)
+    out, n = _decode(ops, z, dec, D, True, flags=PSVAE_NORMALIZE_DECODER)
+    assert n == 4 + 2
+    assert_close(out.norm(dim=1).cpu(), torch.ones(N), 1e-5, "unit rows")
+    for lo, hi in ((0, 64), (65530, 65600), (N - 30, N)):
+        ref = O.decode(p, z[lo:hi].cpu())
+        ref = ref / ref.norm(dim=1, keepdim=True)
+        assert_close(out[lo:hi].cpu(), ref, 1e-4, f"rows {lo}:{hi} vs oracle")
+
+
+def test_small_and_conditional_decodes_keep_the_per_layer_path():
+    """below 16,384 rows the persistent kernel cannot fill the chip, and the conditional table rides the decoder.0
+    epilogue of the per-layer path: both must not take the fused kernel"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z = 256, 64
+    p = O.init_params(D, Z, 2)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(4096 * Z, 8, 0, DEV).reshape(4096, Z)
+    _, n = _decode(ops, z, dec, D, True)
+    assert n == 3
+    N = 20000
+    z = ops.philox_normal(N * Z, 9, 0, DEV).reshape(N, Z)
+    g = torch.Generator().manual_seed(0)
+    tab = torch.randn(6, 512, generator=g).to(DEV)
+    gender = torch.randint(0, 2, (N,), generator=g, dtype=torch.int32).to(DEV)
+    age = torch.randint(0, 4, (N,), generator=g, dtype=torch.int32).to(DEV)
+    out, n = _decode(ops, z, dec, D, True, cond_tab=tab, gender=gender, age=age)
+    assert n == 3
+    plain, n2 = _decode(ops, z, dec, D, True)
+    assert n2 == 4
+    assert not torch.equal(out, plain)
+
+
+def test_fused_decode_through_the_model_api():
+    """VAEModel.decode / .sample (model.py:65-69, inference.py:25) at sampling sizes go through the fused kernel and
+    match the oracle"""
+    from pseudo_speaker_vae_amd import ops
+    from pseudo_speaker_vae_amd.model import VAEModel
+    D, Z, N = 256, 64, 50_000
+    torch.manual_seed(0)
+    m = VAEModel(D, Z).to(DEV)
+    z = torch.randn(N, Z, device=DEV)
+    with torch.no_grad():
+        out = m.decode(z)
+    torch.cuda.synchronize()
+    assert ops.last_decode_launches() == 4
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = O.decode(p, z[-100:].cpu())
+    assert_close(out[-100:].cpu(), ref, 1e-4, "model.decode tail vs oracle")
