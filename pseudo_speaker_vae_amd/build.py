@@ -18,6 +18,27 @@ SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "elementwise.hip", "bottleneck.hip",
 ARCH = "gfx950"
 
 
+# kernels whose inline-asm register loads must never be spilled (hipcc would store the destination register before the
+# data has landed and reload garbage): file -> substring of the mangled kernel names
+NO_SPILL = {"decode_fused.hip": "decode_fused_bf16_kernel"}
+
+
+def _check_no_spill(src: str, remarks: str) -> None:
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name and NO_SPILL[src] in name and int(m.group(1)) > 0:
+            raise RuntimeError(f"{src}: {name} spills {m.group(1)} vector registers; its asm loads' destinations may be "
+                               f"among them (csrc/decode_fused.hip: the bf16 kernel's latent-row loads)")
+    for line in remarks.splitlines():  # everything that is not a resource remark is a real diagnostic
+        if "kernel-resource-usage" not in line and line.strip() and not line.startswith(" "):
+            sys.stderr.write(line + "\n")
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -56,13 +77,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src in NO_SPILL:  # resource remarks on stderr, checked below
+            cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((subprocess.Popen(cmd), src))
+        procs.append((subprocess.Popen(cmd, stderr=subprocess.PIPE if src in NO_SPILL else None, text=True), src))
         objs.append(obj)
     for p, src in procs:
+        err = p.communicate()[1] if src in NO_SPILL else None
         if p.wait() != 0:
+            if err:
+                sys.stderr.write(err)
             raise RuntimeError(f"hipcc failed on {src}")
+        if err is not None:
+            _check_no_spill(src, err)
     tmp = LIB + f".tmp{os.getpid()}"
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:

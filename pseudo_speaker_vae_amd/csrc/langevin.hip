@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void langevin_mfma_kernel(int64_t N, int C, co
 // Same chain with the W1 fragments in LDS instead of registers: the register-resident form above fills the register file
 // (one wavefront per SIMD), so a step's Philox / softmax / update VALU work and its MFMAs take turns.  Here each lane's
 // fragments are pre-arranged in LDS as contiguous 16-byte pieces in exactly the order the loop consumes them
-//   forward : Wf[s][q][r][m]   (k step s = 4 m' + j', hidden block m)   -> two ds_read_b128 per k step (HB = 8)
+//   forward : Wf[s][m/4][q][r][m%4] (k step s = 4 m' + j', hidden block m) -> two ds_read_b128 per k step (HB = 8)
 //   backward: Wb[s2][q][r][m'] (k step s2 = 4 m + j, feature block m')  -> one ds_read_b128 per k step (ZB = 4)
 // (a wavefront reads 64 consecutive pieces: conflict-free), the kernel needs < 128 registers, and 512-thread persistent
 // workgroups put four wavefronts on every SIMD: one wavefront's VALU work runs under the others' MFMAs.
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(512, 4) void langevin_mfma_lds_kernel(int64_t N, in
                                                                    float* __restrict__ history) {
     constexpr int ZD = 16 * ZB, HD = 16 * HB;
     extern __shared__ __attribute__((aligned(16))) float lsm[];
-    float* sWf = lsm;                       // [4 ZB][4][16][HB]
+    float* sWf = lsm;                       // [4 ZB][HB/4][4][16][4]
     float* sWb = sWf + 4 * ZB * 64 * HB;    // [4 HB][4][16][ZB]
     float* sW2 = sWb + 4 * HB * 64 * ZB;    // [C][HD]
     float* sb1 = sW2 + LV_MAXC * HD;        // [HD]
     float* sb2 = sb1 + HD;                  // [C]
     for (int i = threadIdx.x; i < 4 * ZB * 64 * HB; i += 512) {
-        const int m = i % HB, rr_ = (i / HB) % 16, qq = (i / (HB * 16)) % 4, s_ = i / (HB * 64);
+        const int m = 4 * ((i >> 8) % (HB / 4)) + (i & 3), rr_ = (i >> 2) & 15, qq = (i >> 6) & 3, s_ = i / (HB * 64);
         sWf[i] = W1[(size_t)(16 * m + rr_) * ZD + 16 * (s_ >> 2) + 4 * qq + (s_ & 3)];
     }
     for (int i = threadIdx.x; i < 4 * HB * 64 * ZB; i += 512) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 4) void langevin_mfma_lds_kernel(int64_t N, in
     const float drift = 0.5f * step_size * step_size, nsc = step_size * noise_weight;
     const uint64_t blocks_per_step = (uint64_t)((N * ZD + 3) / 4);
     const int64_t ngroups = (N + 15) / 16;
-    const float* __restrict__ myWf = sWf + (q * 16 + r) * HB;
+    const float* __restrict__ myWf = sWf + lane * 4;
     const float* __restrict__ myWb = sWb + (q * 16 + r) * ZB;
     for (int64_t g = (int64_t)blockIdx.x * 8 + wave; g < ngroups; g += (int64_t)gridDim.x * 8) {
         const int64_t row = g * 16 + r;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512, 4) void langevin_mfma_lds_kernel(int64_t N, in
                 // fragment reads to the top (it did: 768 B of scratch per lane at the 128-register budget)
                 f32x4 wn[HB / 4];
 #pragma unroll
-                for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + 4 * m4);
+                for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + 256 * m4);
 #pragma unroll
                 for (int s = 0; s < 4 * ZB; ++s) {
                     f32x4 w[HB / 4];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512, 4) void langevin_mfma_lds_kernel(int64_t N, in
                     for (int m4 = 0; m4 < HB / 4; ++m4) w[m4] = wn[m4];
                     if (s + 1 < 4 * ZB) {
 #pragma unroll
-                        for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + (s + 1) * 64 * HB + 4 * m4);
+                        for (int m4 = 0; m4 < HB / 4; ++m4) wn[m4] = *reinterpret_cast<const f32x4*>(myWf + (s + 1) * 64 * HB + 256 * m4);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

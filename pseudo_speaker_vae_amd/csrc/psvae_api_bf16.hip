@@ -357,6 +357,16 @@ int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const flo
     u16* d2 = reinterpret_cast<u16*>(base + off); off += align_up((size_t)c * H * 2, 256);
     float* yn = reinterpret_cast<float*>(base + off);
     const bool normalize = flags & PSVAE_NORMALIZE_DECODER;
+    if (decode_fused_bf16_ok(N, (int)Z, (int)D)) {
+        // all three layers in one kernel (decode_fused.hip); the packed bf16 weights take the place of Wb0..Wb2
+        RET_IF(launch_decode_fused_bf16(N, (int)Z, (int)D, z, dec6, x_hat, Wb0, s));
+        if (normalize)
+            for (int64_t r0 = 0; r0 < N; r0 += c) {
+                const int n = (int)((N - r0) < c ? (N - r0) : c);
+                RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+            }
+        return 0;
+    }
     for (int64_t r0 = 0; r0 < N; r0 += c) {
         const int n = (int)((N - r0) < c ? (N - r0) : c);
         {   // casts: the chunk of z, and (first chunk only) the three weights

@@ -282,5 +282,8 @@ bool decode_fused_ok(int64_t N, int Z, int D);
 size_t decode_fused_pack_floats(int Z, int D);
 hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat, float* wp,
                                hipStream_t s);
+bool decode_fused_bf16_ok(int64_t N, int Z, int D);
+hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
+                                    unsigned short* wp, hipStream_t s);
 
 }  // namespace psvae

@@ -104,3 +104,58 @@ def test_fused_decode_through_the_model_api():
     p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = O.decode(p, z[-100:].cpu())
     assert_close(out[-100:].cpu(), ref, 1e-4, "model.decode tail vs oracle")
+
+
+BF16_TOL = 4e-3  # tests/test_gpu_bf16.py: a bf16-neighbour flip of a hidden activation is 2^-8 of that element
+
+
+@pytest.mark.parametrize("D,Z,N", [(256, 64, 32768), (256, 64, 32768 + 77), (128, 32, 40001), (512, 64, 33000),
+                                   (128, 64, 70001), (512, 32, 32769), (256, 32, 131072 + 5)])
+def test_fused_bf16_decode_matches_emulation_and_per_layer_path(D, Z, N):
+    """psvae_decode_bf16 at N >= 32,768 rows runs the fused bf16 kernel (same rounding points as the per-layer path: z,
+    weights and the two hidden activations to bf16 round-to-nearest-even, fp32 accumulation, biases and x_hat); against
+    the oracle's bf16 emulation on slices and the per-layer path on all rows.  The two HIP paths sum in different orders,
+    so a hidden activation near a rounding boundary may land on the other bf16 neighbour: the bound is the bf16 one, and
+    the mean difference shows such flips are rare."""
+    from pseudo_speaker_vae_amd import ops
+    p = O.init_params(D, Z, N % 5)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(N * Z, 4, 0, DEV).reshape(N, Z)
+    out = torch.full((N + 1, D), float("nan"), device=DEV)
+    os.environ.pop("PSVAE_DECODE_UNFUSED", None)
+    fused = ops.decode_bf16(z, dec, D, out=out[:N])
+    torch.cuda.synchronize()
+    assert torch.isnan(out[N]).all(), "wrote past the last row"
+    assert torch.isfinite(fused).all()
+    os.environ["PSVAE_DECODE_UNFUSED"] = "1"
+    try:
+        per_layer = ops.decode_bf16(z, dec, D)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("PSVAE_DECODE_UNFUSED", None)
+    assert not torch.equal(fused, per_layer), "both calls took the same path"
+    assert_close(fused.cpu(), per_layer.cpu(), BF16_TOL, "fused vs per-layer bf16, all rows", elementwise=False)
+    assert float((fused - per_layer).abs().mean() / per_layer.pow(2).mean().sqrt()) < 2e-5
+    for lo, hi in ((0, 140), (N // 2 - 3, N // 2 + 130), (N - 150, N)):  # incl. the ragged last tile
+        ref = O.decode_bf16(p, z[lo:hi].cpu(), False)
+        assert_close(fused[lo:hi].cpu(), ref, BF16_TOL, f"rows {lo}:{hi} vs bf16 emulation", elementwise=False)
+
+
+def test_fused_bf16_decode_keeps_the_per_layer_path_where_it_does_not_fit():
+    """Z = 128 (the latent rows in flight do not fit the register file beside 384 accumulator / activation registers) and
+    small calls stay on the per-layer path and stay correct"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z, N = 256, 128, 40000
+    p = O.init_params(D, Z, 3)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    z = ops.philox_normal(N * Z, 4, 0, DEV).reshape(N, Z)
+    a = ops.decode_bf16(z, dec, D)
+    os.environ["PSVAE_DECODE_UNFUSED"] = "1"
+    try:
+        b = ops.decode_bf16(z, dec, D)
+    finally:
+        os.environ.pop("PSVAE_DECODE_UNFUSED", None)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = O.decode_bf16(p, z[-64:].cpu(), False)
+    assert_close(a[-64:].cpu(), ref, BF16_TOL, "tail vs bf16 emulation", elementwise=False)
