@@ -254,34 +254,29 @@ hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const fl
 }
 
 // ===================================================================================================================
-// bf16 variant (psvae_decode_bf16: bf16 operands and hidden activations, fp32 accumulation / biases / x_hat).
-// Same transposed scheme on v_mfma_f32_16x16x32_bf16: lane (r, q) supplies 8 k slots of W row 16 m + r (A) and of
-// activation row r (B) and receives outputs 16 m + 4q + j of row r.  The k slots of an MFMA can be assigned freely as long
-// as both operands agree, so slot (q, e) of k step kb is feature 32 kb + 16 (e / 4) + 4 q + (e % 4): a lane's B operand is
-// then its own accumulator blocks 2 kb and 2 kb + 1 of the previous layer, ReLU'd and rounded to bf16 in place
+// bf16 variant (psvae_decode_bf16: bf16 operands and hidden activations, fp32 accumulation / biases / x_hat), on
+// v_mfma_f32_16x16x32_bf16, transposed as above: lane (r, q) supplies 8 k slots of W row 16 m + r (A) and of activation
+// row r (B) and receives outputs 16 m + 4q + j of row r.  The k slots of an MFMA can be assigned freely as long as both
+// operands agree, so slot (q, e) of k step kb is feature 32 kb + 16 (e / 4) + 4 q + (e % 4): a lane's B operand is then
+// its own accumulator blocks 2 kb and 2 kb + 1 of the previous layer, ReLU'd and rounded to bf16 in place
 // (v_cvt_pk_bf16_f32 + v_pk_max_i16) -- again no shuffle between layers -- and the permutation is baked into the
-// packed weights  Wp[kb][m][lane][e] = bf16(W[16 m + r][32 kb + 16 (e / 4) + 4 q + (e % 4)]).
-// An MFMA here is 16 cycles for a 16-byte fragment read, so every fragment is used for TWO row groups (a wavefront owns
-// 32 rows: 256 accumulator + 128 packed-activation registers): 128 B/clk/CU of LDS reads against the 256 the array
-// delivers.  Chunk = one k step (32 KB for 512 outputs), three LDS buffers, one barrier per chunk as above.
+// packed weights.
+//
+// An MFMA here is 16 cycles, so the fp32 kernel's organisation (a wavefront owns rows, every weight byte goes global ->
+// LDS -> registers) does not carry over: built that way (LDS-DMA three chunks ahead into a ring of four 32 KB buffers,
+// hand-counted vmcnt, two row groups per fragment read) it ran 1 M rows in 0.84 ms, paying one DMA issue (60-185 cycles)
+// per KB of weights and one barrier per k step.  Here a wavefront owns a FEATURE slice instead: the 128 rows of a tile
+// are shared by the workgroup's four wavefronts, wavefront w computes output blocks [8w, 8w + 8) of each hidden layer
+// (D / 64 blocks of the output layer) for ALL 128 rows.  Its weight fragments are needed by no other wavefront and go
+// straight from L2 into registers (plain 16-byte loads, two k steps ahead, each used for 8 row groups); the ACTIVATIONS
+// are what is shared: one 128 KB LDS image [k step][row group][lane][8 bf16], written by the wavefront that produced
+// those features -- the C-to-B register identity makes the write lane-linear -- and read as B fragments (8 ds_read_b128
+// per 64 MFMAs).  Eight barriers per tile, no DMA, no asm loads; x_hat leaves through the (then dead) image as whole rows.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 nbf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void pack_decode_weights_bf16_kernel(const float* __restrict__ W,
-                                                                       unsigned short* __restrict__ Wp, int OUT, int IN) {
-    const int MB = OUT / 16;
-    const long n = (long)OUT * IN;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int e = (int)(i & 7), r = (int)((i >> 3) & 15), q = (int)((i >> 7) & 3);
-        const long t = i >> 9;
-        const int m = (int)(t % MB), kb = (int)(t / MB);
-        const __bf16 b = (__bf16)W[(size_t)(16 * m + r) * IN + 32 * kb + 16 * (e >> 2) + 4 * q + (e & 3)];
-        Wp[i] = *reinterpret_cast<const unsigned short*>(&b);
-    }
-}
 
 // two fp32 accumulator blocks -> one B operand: (ReLU,) round to nearest even, pack
 template <bool RELU>
@@ -316,230 +311,227 @@ struct DecodeFusedBfArgs {
     int Z, D;
 };
 
-// s_waitcnt vmcnt(n) with n known after unrolling (the asm immediate must be a literal)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define PSVAE_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        PSVAE_VM(0) PSVAE_VM(4) PSVAE_VM(8) PSVAE_VM(12) PSVAE_VM(16) PSVAE_VM(20) PSVAE_VM(24)
-#undef PSVAE_VM
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// Wp[layer][wavefront w][k step kb][block mi][lane][e] = bf16(W[16 (MBW w + mi) + r][32 kb + 16 (e / 4) + 4 q + (e % 4)])
+__global__ __launch_bounds__(256) void pack_decode_weights_bf16w_kernel(const float* __restrict__ W,
+                                                                        unsigned short* __restrict__ Wp, int OUT, int IN) {
+    const int MBW = OUT / 64, KB = IN / 32;  // blocks per wavefront, k steps
+    const long n = (long)OUT * IN;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int e = (int)(i & 7), r = (int)((i >> 3) & 15), q = (int)((i >> 7) & 3);
+        const long t = i >> 9;
+        const int mi = (int)(t % MBW), kb = (int)((t / MBW) % KB), w = (int)(t / ((long)MBW * KB));
+        const int m = MBW * w + mi;
+        const __bf16 b = (__bf16)W[(size_t)(16 * m + r) * IN + 32 * kb + 16 * (e >> 2) + 4 * q + (e & 3)];
+        Wp[i] = *reinterpret_cast<const unsigned short*>(&b);
     }
 }
 
-// The weight stream of the bf16 kernel: a chunk lasts 64 MFMAs x 16 cycles, far less than an L2 round trip, and the
-// register file has no room for a second chunk in flight -- the chunks go global -> LDS directly (LDS-DMA,
-// global_load_lds_dwordx4: one 1 KB piece per wave-instruction, no VGPRs), THREE chunks ahead into a ring of four
-// buffers.  hipcc does not see these loads (inline asm), so the waits are counted by hand: loads return in order, so
-// "my pieces of chunk c + 1 have landed" is vmcnt(pieces issued after them); pending x_hat stores only make a counted wait
-// conservative.  The latent rows of the next tile are asm loads too (anything hipcc counts would drain the DMA queue
-// with a vmcnt(0)); they are ordered behind a DMA issue so that only the chunk issued AFTER them queues behind their HBM
-// latency.
-template <int ZK, int DB, int GS>  // Z = 32 ZK, D = 16 DB, hidden = 512; GS output blocks per fragment group
-__global__ __launch_bounds__(256, 1) void decode_fused_bf16_kernel(const DecodeFusedBfArgs a) {
-    constexpr int HB = H / 16, HK = H / 32;        // 32 output blocks, 16 k steps
-    constexpr int CHB = HB * 1024;                 // bytes of a chunk with 512 outputs (one k step)
-    constexpr int NCH = ZK + HK + HK;
-    constexpr int NZ = 2 * ZK * 2;                 // z loads per lane and tile
+template <int ZK, int DBW>  // Z = 32 ZK, D = 64 DBW, hidden = 512
+__global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFusedBfArgs a) {
+    constexpr int HK = H / 32;                       // 16 k steps of a hidden input
+    constexpr int S = ZK + HK + HK;                  // k steps of the whole weight stream per tile
+    constexpr int NA = 3;                            // weight-fragment ring: this step and two ahead
+    constexpr int RPP = DBW == 8 ? 64 : 128;         // rows per x_hat staging pass (D = 512: two passes)
+    constexpr int RS = 256 * DBW + 16;               // bytes of a staged row
+    constexpr int IMG = RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    char* wbuf = reinterpret_cast<char*>(lds);     // [4][CHB]
-    float* sbias = lds + 4 * CHB / 4;              // [512 + 512 + D]
+    char* act = reinterpret_cast<char*>(lds);        // [16 k steps][8 row groups][64 lanes][16 B] = 128 KB; x_hat staging
+    float* sbias = lds + IMG / 4;                    // [512 + 512 + D]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < H; i += 256) { sbias[i] = a.bias0[i]; sbias[H + i] = a.bias1[i]; }
-    for (int i = tid; i < 16 * DB; i += 256) sbias[2 * H + i] = a.bias2[i];
+    for (int i = tid; i < 64 * DBW; i += 256) sbias[2 * H + i] = a.bias2[i];
 
-    auto ch_mbo = [&](int c) -> int { return c < ZK + HK ? HB : DB; };
-    auto ch_off = [&](int c) -> long {  // byte offset of chunk c in the packed weights
-        return c < ZK + HK ? (long)c * CHB : (long)(ZK + HK) * CHB + (long)(c - ZK - HK) * DB * 1024;
-    };
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wbuf;
-    unsigned base[4] = {0u, (unsigned)CHB, 2u * CHB, 3u * CHB};  // chunk u of the cyclic stream lives at base[u % 4]
-    const unsigned voff = 16u * tid;
-    auto dma_piece = [&](int u, int i) {  // piece i of chunk u of the stream (u may run into the next tile)
-        const int cc = u % NCH;
-        if (i >= ch_mbo(cc) / 4) return;
-        const char* src = reinterpret_cast<const char*>(a.wp) + ch_off(cc);
-        const unsigned dst = lds0 + base[u % 4] + 1024u * wave + 4096u * i;
-        const unsigned vo = voff + 4096u * i;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(vo), "s"(src), "s"(dst) : "memory");
-    };
-    auto dma = [&](int u) {
+    // this wavefront's weight stream: step s has MB(s) fragments of 1 KB (16 B per lane), wave-major inside a layer
+    auto mb_of = [&](int s) -> int { return s < ZK + HK ? 8 : DBW; };
+    const unsigned short* wl0 = a.wp + (size_t)wave * (ZK * 8 * 512) + lane * 8;
+    const unsigned short* wl1 = a.wp + (size_t)H * a.Z + (size_t)wave * (HK * 8 * 512) + lane * 8;
+    const unsigned short* wl2 = a.wp + (size_t)H * a.Z + (size_t)H * H + (size_t)wave * (HK * DBW * 512) + lane * 8;
+    bf16x8 wa[NA][8];
+    // (one running pointer, opaque to the optimiser and typed global: per-fragment addresses are loop invariants the
+    //  compiler would otherwise precompute and spill by the hundred -- see the fp32 kernel)
+    typedef const __attribute__((address_space(1))) unsigned short gu16;
+    typedef const __attribute__((address_space(1))) bf16x8 gbf16x8;
+    gu16* wsrc = nullptr;
+    auto wfetch = [&](int s) {  // s in [0, S), called in stream order: fragments of k step s into ring slot s % NA
+        if (s == 0) wsrc = (gu16*)wl0;
+        if (s == ZK) wsrc = (gu16*)wl1;
+        if (s == ZK + HK) wsrc = (gu16*)wl2;
+        asm volatile("" : "+v"(wsrc));
 #pragma unroll
-        for (int i = 0; i < HB / 4; ++i) dma_piece(u, i);
+        for (int mi = 0; mi < 8; ++mi)
+            if (mi < mb_of(s)) wa[s % NA][mi] = *(gbf16x8*)(wsrc + mi * 512);
+        wsrc += mb_of(s) * 512;
     };
-    bf16x8 w[2][GS];  // fragment groups of GS output blocks: the one being multiplied and the one after it
-    auto fragg = [&](int set, int u, int g) {
-        const char* wl = wbuf + base[u % 4] + g * (GS * 1024) + lane * 16;
+    bf16x8 bb[2][8];
+    auto bfetch = [&](int set, int kb) {  // B fragments of k step kb: all 8 row groups
+        const char* src = act + kb * 8192 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < GS; ++i) w[set][i] = *reinterpret_cast<const bf16x8*>(wl + 1024 * i);
+        for (int g = 0; g < 8; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
     };
 
     const long ntiles = (a.N + 127) / 128;
-    auto zrow = [&](long tile, int g) -> long {
-        const long row = tile * 128 + wave * 32 + 16 * g + r;
-        return row < a.N ? row : a.N - 1;
-    };
-    f32x4 zn[2][ZK][2];  // the next tile's latent rows (fp32)
+    f32x4 zn[2][ZK][2];  // the next tile's latent rows of this wavefront's two row groups (fp32)
     auto zfetch = [&](long tile) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const float* zp = a.z + zrow(tile, g) * a.Z + 4 * q;
+            long row = tile * 128 + 32 * wave + 16 * g + r;
+            row = row < a.N ? row : a.N - 1;
+            const float* zp = a.z + row * a.Z + 4 * q;
 #pragma unroll
-            for (int kb = 0; kb < ZK; ++kb)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(zn[g][kb][h]) : "v"(zp + 32 * kb + 16 * h) : "memory");
+            for (int kb = 0; kb < ZK; ++kb) {
+                zn[g][kb][0] = *reinterpret_cast<const f32x4*>(zp + 32 * kb);
+                zn[g][kb][1] = *reinterpret_cast<const f32x4*>(zp + 32 * kb + 16);
+            }
         }
-    };
-    auto zfence = [&]() {  // no consumer of zn above this point
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int kb = 0; kb < ZK; ++kb) asm volatile("" : "+v"(zn[g][kb][0]), "+v"(zn[g][kb][1]));
     };
     zfetch(blockIdx.x);
-    dma(0);
-    dma(1);
-    dma(2);
-    wait_vmcnt(0);
-    __syncthreads();  // (also publishes sbias; nothing is in flight here)
-    fragg(0, 0, 0);
+    wfetch(0);
+    wfetch(1);
+    __syncthreads();  // sbias
 #ifdef PSVAE_STAMP
-    // cycle stamps of the workgroup's last tile, unconditional (a branch per stamp cuts the block and costs ~100 spills), kept in SGPRs (the kernel has no vector registers to spare: a spill would break the
-    // asm loads' contract)
-    unsigned long long st_[7] = {0, 0, 0, 0, 0, 0, 0};
-#define DSTAMP(K) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[K]))
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RSTAMP(K) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[K]))
 #else
-#define DSTAMP(K) do {} while (0)
+#define RSTAMP(K) do {} while (0)
 #endif
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int c = 0;
-        f32x4 acc[2][HB];
-        bf16x8 ap[2][HK];
-        DSTAMP(0);
-        // one chunk = one k step over MBO output blocks, both row groups, in fragment groups of 8 blocks:
-        //   group g: request the next group's fragments (the next chunk's group 0 after the last), multiply;
-        //   after group 0: wait for MY pieces of chunk c + 1, the chunk's one barrier (every wavefront's pieces of c + 1
-        //   are in LDS, every wavefront is done with chunk c - 1), then chunk c + 3 is requested into c - 1's buffer.
-        // `zc`: the chunk after whose DMA issue the next tile's latent rows are requested
-        auto chunk = [&](auto MBOc, const bf16x8& b0, const bf16x8& b1, int zc) {
-            constexpr int MBO = decltype(MBOc)::value;
-            constexpr int G = MBO / GS;
-            static_assert(G % 2 == 0, "the fragment sets alternate by group parity");
+        RSTAMP(0);
+        // ---- the tile's latent rows -> B image (k steps 0 .. ZK-1 of `act`); every wavefront is past the previous tile's
+        //      last read of `act` (barrier at the end of the loop body)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (g + 1 < G) fragg((g + 1) & 1, c, g + 1);
-                else fragg(0, c + 1, 0);
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int kb = 0; kb < ZK; ++kb)
+                *reinterpret_cast<bf16x8*>(act + (kb * 8 + 2 * wave + g) * 1024 + lane * 16) =
+                    pack_bf16x8<false>(zn[g][kb][0], zn[g][kb][1]);
+        __syncthreads();
+        f32x4 acc[8][8];  // [block of this wavefront][row group]
+        int s = 0;        // k step of the weight stream
+        // one layer: KB k steps over MB blocks x 8 row groups; the bias is the first step's C operand
+        auto layer = [&](auto KBc, auto MBc, const float* bias) {
+            constexpr int KB = decltype(KBc)::value, MB = decltype(MBc)::value;
+            f32x4 bv[MB];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) bv[mi] = *reinterpret_cast<const f32x4*>(bias + 16 * (MB * wave + mi) + 4 * q);
+            bfetch(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb, ++s) {
+                __builtin_amdgcn_sched_barrier(0);  // (keeps the compiler from hoisting every step's loads to the top)
+                // the stream is cyclic (the tile's last two steps fetch the next tile's first two) when the ring closes,
+                // S % NA == 0; otherwise those two fetches wait until the tile's last MFMA has issued (below)
+                if (s + 2 < S) wfetch(s + 2);
+                else if (S % NA == 0) wfetch(s + 2 - S);
+                if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < GS; ++i) {
-                    acc[0][GS * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g & 1][i], b0, acc[0][GS * g + i], 0, 0, 0);
-                    acc[1][GS * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g & 1][i], b1, acc[1][GS * g + i], 0, 0, 0);
-                    if (g >= 1 && (g - 1) * GS + i < HB / 4) {  // chunk c + 3's pieces go out between the MFMAs after the barrier
-                        dma_piece(c + 3, (g - 1) * GS + i);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if (g == G - 1) {  // a short chunk (D = 128) has fewer slots than a 512-output chunk has pieces
+                for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-                    for (int pce = (G - 1) * GS; pce < HB / 4; ++pce) dma_piece(c + 3, pce);
-                }
-                if (c == zc && g == (HB / 4 + GS - 1) / GS) zfetch(tile + gridDim.x);  // (right behind the last piece)
-                __builtin_amdgcn_sched_barrier(0);
-                if (g == 0) {
-                    // outstanding behind chunk c + 1's pieces: chunk c + 2's, and the latent rows if they were requested
-                    // after chunk c + 1's or c + 2's issue
-                    wait_vmcnt(ch_mbo((c + 2) % NCH) / 4 + ((c == zc + 1 || c == zc + 2) ? NZ : 0));
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    for (int g = 0; g < 8; ++g)
+                        acc[mi][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % NA][mi], bb[kb & 1][g],
+                                                                            kb == 0 ? bv[mi] : acc[mi][g], 0, 0, 0);
             }
-            ++c;
+            __builtin_amdgcn_sched_barrier(0);
         };
-        constexpr int ZC = ZK;  // first chunk of layer 1
-        // ---- layer 0: Z -> 512 ----
-        zfence();
+        // hidden activations: ReLU, round to bf16, into the B image of the next layer (this wavefront produced the features
+        // of k steps 4 wave .. 4 wave + 3)
+        auto publish = [&]() {
+            __syncthreads();  // every wavefront has read the previous image
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 t[8];  // (eight independent convert chains, then their writes: one chain at a time is latency-bound)
 #pragma unroll
-            for (int kb = 0; kb < ZK; ++kb) ap[g][kb] = pack_bf16x8<false>(zn[g][kb][0], zn[g][kb][1]);
+                for (int g = 0; g < 8; ++g) t[g] = pack_bf16x8<true>(acc[2 * kk][g], acc[2 * kk + 1][g]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < HB; ++m) acc[0][m] = acc[1][m] = *reinterpret_cast<const f32x4*>(sbias + 16 * m + 4 * q);
+                for (int g = 0; g < 8; ++g)
+                    *reinterpret_cast<bf16x8*>(act + ((4 * wave + kk) * 8 + g) * 1024 + lane * 16) = t[g];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        RSTAMP(1);
+        layer(std::integral_constant<int, ZK>{}, std::integral_constant<int, 8>{}, sbias);
+        RSTAMP(2);
+        publish();
+        RSTAMP(3);
+        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{}, sbias + H);
+        RSTAMP(4);
+        publish();
+        RSTAMP(5);
+        zfetch(tile + gridDim.x);
+        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, DBW>{}, sbias + 2 * H);
+        RSTAMP(6);
+        if (S % NA != 0) {  // (their latency runs under the stores, the barrier and the latent rows' write)
+            wfetch(0);
+            wfetch(1);
+        }
+        // x_hat: a lane holds 4 consecutive features of 16 different rows per block -- stored as it stands, every store
+        // instruction would touch 16 rows with 64 bytes each (store-issue bound: 8.8k of the tile's 48k cycles).  The tile goes
+        // through LDS instead (the image is dead once every wavefront has left layer 2; rows padded by 16 B so the 16 r lanes
+        // hit different banks) and leaves as whole rows: 1 KB contiguous per store instruction.
 #pragma unroll
-        for (int kb = 0; kb < ZK; ++kb) chunk(std::integral_constant<int, HB>{}, ap[0][kb], ap[1][kb], ZC);
-        DSTAMP(1);
+        for (int ps = 0; ps < 128 / RPP; ++ps) {
+            __syncthreads();  // image (or the previous pass) no longer read
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+            for (int g = ps * (RPP / 16); g < (ps + 1) * (RPP / 16); ++g)
 #pragma unroll
-            for (int kb = 0; kb < HK; ++kb) ap[g][kb] = pack_bf16x8<true>(acc[g][2 * kb], acc[g][2 * kb + 1]);
-        DSTAMP(2);
-        // ---- layer 1: 512 -> 512 ----
+                for (int mi = 0; mi < DBW; ++mi)
+                    *reinterpret_cast<f32x4*>(act + (16 * (g - ps * (RPP / 16)) + r) * RS + (16 * (DBW * wave + mi) + 4 * q) * 4) =
+                        acc[mi][g];
+            __syncthreads();
+            // (reads in batches of 8 ahead of their stores: row by row, every store would wait out an LDS round trip)
+            constexpr int NI = DBW >= 4 ? (RPP / 4) * (DBW / 4) : RPP / 8;  // store instructions per wavefront and pass
 #pragma unroll
-        for (int m = 0; m < HB; ++m) acc[0][m] = acc[1][m] = *reinterpret_cast<const f32x4*>(sbias + H + 16 * m + 4 * q);
+            for (int i0 = 0; i0 < NI; i0 += 8) {
+                f32x4 v[8];
 #pragma unroll
-        for (int kb = 0; kb < HK; ++kb) chunk(std::integral_constant<int, HB>{}, ap[0][kb], ap[1][kb], ZC);
-        DSTAMP(3);
+                for (int i = 0; i < 8; ++i) {
+                    const int it = i0 + i;
+                    const int rl = DBW >= 4 ? (RPP / 4) * wave + it / (DBW >= 4 ? DBW / 4 : 1) : (RPP / 4) * wave + 2 * it + (lane >> 5);
+                    const int pc = DBW >= 4 ? it % (DBW >= 4 ? DBW / 4 : 1) : 0;
+                    v[i] = *reinterpret_cast<const f32x4*>(act + rl * RS + pc * 1024 + (DBW >= 4 ? lane : (lane & 31)) * 16);
+                }
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int kb = 0; kb < HK; ++kb) ap[g][kb] = pack_bf16x8<true>(acc[g][2 * kb], acc[g][2 * kb + 1]);
-        DSTAMP(4);
-        // ---- layer 2: 512 -> D, fp32 out ----
-#pragma unroll
-        for (int m = 0; m < DB; ++m) acc[0][m] = acc[1][m] = *reinterpret_cast<const f32x4*>(sbias + 2 * H + 16 * m + 4 * q);
-#pragma unroll
-        for (int kb = 0; kb < HK; ++kb) chunk(std::integral_constant<int, DB>{}, ap[0][kb], ap[1][kb], ZC);
-        DSTAMP(5);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const long row = tile * 128 + wave * 32 + 16 * g + r;
-            if (row < a.N) {
-#pragma unroll
-                for (int m = 0; m < DB; ++m) *reinterpret_cast<f32x4*>(a.x_hat + row * a.D + 16 * m + 4 * q) = acc[g][m];
+                for (int i = 0; i < 8; ++i) {
+                    const int it = i0 + i;
+                    const int rl = DBW >= 4 ? (RPP / 4) * wave + it / (DBW >= 4 ? DBW / 4 : 1) : (RPP / 4) * wave + 2 * it + (lane >> 5);
+                    const int pc = DBW >= 4 ? it % (DBW >= 4 ? DBW / 4 : 1) : 0;
+                    const long row = tile * 128 + ps * RPP + rl;
+                    if (row < a.N)
+                        *reinterpret_cast<f32x4*>(a.x_hat + row * a.D + pc * 256 + (DBW >= 4 ? lane : (lane & 31)) * 4) = v[i];
+                }
             }
         }
-        const unsigned b0 = base[NCH % 4], b1 = base[(NCH + 1) % 4], b2 = base[(NCH + 2) % 4], b3 = base[(NCH + 3) % 4];
-        base[0] = b0; base[1] = b1; base[2] = b2; base[3] = b3;
-        DSTAMP(6);
-#ifdef PSVAE_STAMP
-#endif
+        __syncthreads();  // the staged rows have been read before the next tile's latent rows overwrite them
+        RSTAMP(7);
     }
 #ifdef PSVAE_STAMP
     if (tid == 0 && blockIdx.x == 7)
-        for (int i = 0; i < 7; ++i) g_dstamp[i] = st_[i];
+        for (int i = 0; i < 8; ++i) g_dstamp[i] = st_[i];
 #endif
-    wait_vmcnt(0);  // the stream ran ahead into a tile that does not exist: its DMA must not outlive the workgroup's LDS
 }
 
-bool decode_fused_bf16_ok(int64_t N, int Z, int D) {
-    const bool off = getenv("PSVAE_DECODE_UNFUSED") != nullptr;
-    const long minrows = getenv("PSVAE_DECODE_FUSED_MIN") ? atol(getenv("PSVAE_DECODE_FUSED_MIN")) : 32768;
-    // Z = 128 does not fit: 16 more registers of latent rows in flight spill, and a spilled asm-load destination is
-    // garbage (hipcc stores it before the data has landed)
-    return !off && N >= minrows && (Z == 64 || Z == 32) && (D == 256 || D == 512 || D == 128);
-}
-
-template <int ZK, int DB, int GS>
-static hipError_t launch_decode_fused_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * (H / 16) * 1024 + (size_t)(2 * H + 16 * DB) * sizeof(float);
+template <int ZK, int DBW>
+static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
+    constexpr int RPP = DBW == 8 ? 64 : 128, RS = 256 * DBW + 16;
+    constexpr size_t lds = (size_t)(RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024) + (size_t)(2 * H + 64 * DBW) * sizeof(float);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_fused_bf16_kernel<ZK, DB, GS>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) return attr_err;
     const long ntiles = (a.N + 127) / 128;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL((decode_fused_bf16_kernel<ZK, DB, GS>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW>), dim3(grid), dim3(256), lds, s, a);
 #ifdef PSVAE_STAMP
     {
         unsigned long long h[8];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dstamp), sizeof(h)) == hipSuccess) {
-            printf("decode bf16 stamps (cycles): L0 | relu+pack | L1 | relu+pack | L2 | stores:");
-            for (int i = 1; i < 7; ++i) printf(" %llu", h[i] - h[i - 1]);
+            printf("decode bf16 (feature-slice form) stamps (cycles): z image | L0 | publish | L1 | publish | L2 | stores:");
+            for (int i = 1; i < 8; ++i) printf(" %llu", h[i] - h[i - 1]);
             printf("\n");
         }
     }
@@ -547,26 +539,34 @@ static hipError_t launch_decode_fused_bf16_t(const DecodeFusedBfArgs& a, hipStre
     return hipGetLastError();
 }
 
-// pack (cast + permute) the three weight matrices into `wp` ((H Z + H H + D H) bf16) and run the fused kernel
-hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
-                                    unsigned short* wp, hipStream_t s) {
+hipError_t launch_decode_rows_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
+                                   unsigned short* wp, hipStream_t s) {
     unsigned short* wp0 = wp;
     unsigned short* wp1 = wp0 + (size_t)H * Z;
     unsigned short* wp2 = wp1 + (size_t)H * H;
-    hipLaunchKernelGGL(pack_decode_weights_bf16_kernel, dim3(128), dim3(256), 0, s, dec6[0], wp0, H, Z);
-    hipLaunchKernelGGL(pack_decode_weights_bf16_kernel, dim3(256), dim3(256), 0, s, dec6[2], wp1, H, H);
-    hipLaunchKernelGGL(pack_decode_weights_bf16_kernel, dim3(256), dim3(256), 0, s, dec6[4], wp2, D, H);
+    hipLaunchKernelGGL(pack_decode_weights_bf16w_kernel, dim3(128), dim3(256), 0, s, dec6[0], wp0, H, Z);
+    hipLaunchKernelGGL(pack_decode_weights_bf16w_kernel, dim3(256), dim3(256), 0, s, dec6[2], wp1, H, H);
+    hipLaunchKernelGGL(pack_decode_weights_bf16w_kernel, dim3(256), dim3(256), 0, s, dec6[4], wp2, D, H);
     DecodeFusedBfArgs a{};
     a.z = z; a.x_hat = x_hat; a.wp = wp; a.bias0 = dec6[1]; a.bias1 = dec6[3]; a.bias2 = dec6[5];
     a.N = N; a.Z = Z; a.D = D;
-    static const int gs = getenv("PSVAE_DECODE_BF16_GS") ? atoi(getenv("PSVAE_DECODE_BF16_GS")) : 8;
-#define PSVAE_DFB(ZK, DB)                                                                        \
-    if (Z == 32 * ZK && D == 16 * DB)                                                            \
-        return (gs == 4 || DB == 8) ? launch_decode_fused_bf16_t<ZK, DB, 4>(a, s)                \
-                                    : launch_decode_fused_bf16_t<ZK, (DB == 8 ? 16 : DB), 8>(a, s)
-    PSVAE_DFB(2, 16); PSVAE_DFB(1, 16); PSVAE_DFB(2, 8); PSVAE_DFB(2, 32); PSVAE_DFB(1, 8); PSVAE_DFB(1, 32);
-#undef PSVAE_DFB
+#define PSVAE_DRB(ZK, DBW) if (Z == 32 * ZK && D == 64 * DBW) return launch_decode_rows_bf16_t<ZK, DBW>(a, s)
+    PSVAE_DRB(2, 4); PSVAE_DRB(1, 4); PSVAE_DRB(4, 4); PSVAE_DRB(2, 2); PSVAE_DRB(1, 2); PSVAE_DRB(4, 2);
+    PSVAE_DRB(2, 8); PSVAE_DRB(1, 8); PSVAE_DRB(4, 8);
+#undef PSVAE_DRB
     return hipErrorInvalidValue;
+}
+
+bool decode_fused_bf16_ok(int64_t N, int Z, int D) {
+    const bool off = getenv("PSVAE_DECODE_UNFUSED") != nullptr;
+    const long minrows = getenv("PSVAE_DECODE_FUSED_MIN") ? atol(getenv("PSVAE_DECODE_FUSED_MIN")) : 32768;
+    return !off && N >= minrows && (Z == 64 || Z == 32 || Z == 128) && (D == 256 || D == 512 || D == 128);
+}
+
+// pack (cast + permute) the three weight matrices into `wp` ((H Z + H H + D H) bf16) and run the fused kernel
+hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
+                                    unsigned short* wp, hipStream_t s) {
+    return launch_decode_rows_bf16(N, Z, D, z, dec6, x_hat, wp, s);
 }
 
 }  // namespace psvae

@@ -120,15 +120,19 @@ int main(void) {
 
 
 def test_build_refuses_a_spilling_asm_load_kernel():
-    """build.py's guard for the fused bf16 decode kernel (its latent-row loads are inline asm: a spilled destination
-    register would be stored before the data lands)"""
+    """build.py's guard for kernels with inline-asm register loads (a spilled destination register would be stored before
+    the data lands); no kernel needs it at present, the mechanism stays tested"""
     import pytest as _pytest
     from pseudo_speaker_vae_amd import build
     ok = ("x.hip:1:1: remark: Function Name: _ZN5psvae24decode_fused_bf16_kernelILi2ELi16ELi8EEEv [-Rpass-analysis=kernel-resource-usage]\n"
           "x.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
           "x.hip:1:1: remark: Function Name: _ZN5psvae19decode_fused_kernelILi8ELi32EEEv [-Rpass-analysis=kernel-resource-usage]\n"
           "x.hip:1:1: remark:     VGPRs Spill: 37 [-Rpass-analysis=kernel-resource-usage]\n")
-    build._check_no_spill("decode_fused.hip", ok)  # the fp32 kernel's loads are compiler-tracked: its spills are legal
-    bad = ok.replace("VGPRs Spill: 0", "VGPRs Spill: 11")
-    with _pytest.raises(RuntimeError, match="spills 11"):
-        build._check_no_spill("decode_fused.hip", bad)
+    build.NO_SPILL["x.hip"] = "decode_fused_bf16_kernel"
+    try:
+        build._check_no_spill("x.hip", ok)  # the other kernel's loads are compiler-tracked: its spills are legal
+        bad = ok.replace("VGPRs Spill: 0", "VGPRs Spill: 11")
+        with _pytest.raises(RuntimeError, match="spills 11"):
+            build._check_no_spill("x.hip", bad)
+    finally:
+        del build.NO_SPILL["x.hip"]

@@ -110,7 +110,8 @@ BF16_TOL = 4e-3  # tests/test_gpu_bf16.py: a bf16-neighbour flip of a hidden act
 
 
 @pytest.mark.parametrize("D,Z,N", [(256, 64, 32768), (256, 64, 32768 + 77), (128, 32, 40001), (512, 64, 33000),
-                                   (128, 64, 70001), (512, 32, 32769), (256, 32, 131072 + 5)])
+                                   (128, 64, 70001), (512, 32, 32769), (256, 32, 131072 + 5), (256, 128, 40000), (512, 128, 33001),
+                                   (128, 128, 32768 + 129)])
 def test_fused_bf16_decode_matches_emulation_and_per_layer_path(D, Z, N):
     """psvae_decode_bf16 at N >= 32,768 rows runs the fused bf16 kernel (same rounding points as the per-layer path: z,
     weights and the two hidden activations to bf16 round-to-nearest-even, fp32 accumulation, biases and x_hat); against
@@ -141,11 +142,9 @@ def test_fused_bf16_decode_matches_emulation_and_per_layer_path(D, Z, N):
         assert_close(fused[lo:hi].cpu(), ref, BF16_TOL, f"rows {lo}:{hi} vs bf16 emulation", elementwise=False)
 
 
-def test_fused_bf16_decode_keeps_the_per_layer_path_where_it_does_not_fit():
-    """Z = 128 (the latent rows in flight do not fit the register file beside 384 accumulator / activation registers) and
-    small calls stay on the per-layer path and stay correct"""
+def test_fused_bf16_decode_small_calls_keep_the_per_layer_path():
     from pseudo_speaker_vae_amd import ops
-    D, Z, N = 256, 128, 40000
+    D, Z, N = 256, 128, 20000
     p = O.init_params(D, Z, 3)
     dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
     z = ops.philox_normal(N * Z, 4, 0, DEV).reshape(N, Z)
