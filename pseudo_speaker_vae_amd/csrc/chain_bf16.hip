@@ -1,0 +1,419 @@
+// Row-chain kernels of the bf16 training pass (BASELINE config 3): a 3-layer MLP -- one encoder (model.py:14-27) or the
+// decoder (model.py:30-36,58-61) -- over a tile of 64 batch rows in ONE launch, organised like the fused bf16 decode
+// (decode_fused.hip, second half): the four wavefronts of a workgroup own FEATURE slices, the tile's activations are
+// shared through one LDS image [k step][row group][lane][8 bf16], weights go straight from L2 to registers.  The
+// per-layer path (gemm_bf16.hip) runs each layer as a launch of 128 x 64 tiles: at B = 4096 that is one round of
+// workgroups per launch whose fetch / MFMA / store-burst phases cannot overlap, and every hidden activation is written
+// and immediately re-read through memory (the forward was 76 of the step's 192 us).  Here a hidden activation leaves the
+// chip once -- as the row-major bf16 copy the backward's weight gradients and ReLU masks need, staged through LDS so
+// that every store instruction writes whole rows -- and is never read back in the forward.
+//
+//   layer 0: in [B, K0] fp32 (x or z; rounded to bf16 on load exactly as the cast / reparam kernels do)
+//            -> 512, + bias (+ table[gender] + table[3 + age]: the one-hot conditioning, fp32), ReLU -> save[0], image
+//   layer 1: 512 -> 512, + bias, ReLU -> save[1], image
+//   layer 2: 512 -> NOUT, + bias -> out [B, NOUT] fp32            (mu / log sigma^2 heads: NOUT = Z)
+//            decoder: out = x_hat, and in the same pass over the staged rows the MSE gradient
+//            gy = bf16(scale * go * (x_hat - x)) and the tile's sum of squared errors (lightning.py:113, BEPI_RECON's job)
+// Same rounding points as the per-layer path; sums in a different order (the bias is the accumulator's initial value),
+// so a hidden activation near a rounding boundary may land on the other bf16 neighbour.
+#include <mutex>
+#include <type_traits>
+
+#include "psvae_common.h"
+
+namespace psvae {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nbf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+namespace {
+
+template <bool RELU>
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    union { bf16x8 v; s16x2 p[4]; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4& s = h ? hi : lo;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            nbf16x2 b = __builtin_convertvector(f32x2{s[2 * t], s[2 * t + 1]}, nbf16x2);
+            s16x2 v = *reinterpret_cast<s16x2*>(&b);
+            if (RELU) v = __builtin_elementwise_max(v, s16x2{0, 0});
+            u.p[2 * h + t] = v;
+        }
+    }
+    return u.v;
+}
+
+constexpr int SROW = 1024 + 16;          // staged row: 512 bf16 (or 256 fp32) + 16 B so the 16 r lanes hit different banks
+
+}  // namespace
+
+// Wp[wavefront w][k step kb][block mi][lane][e] = bf16(W[16 (MBW w + mi) + r][32 kb + 16 (e / 4) + 4 q + (e % 4)]),
+// W [OUT, IN] fp32 row-major, MBW = OUT / 64; grid.y = matrix
+struct ChainPackArgs {
+    const float* W[9];
+    u16* Wp[9];
+    int OUT[9], IN[9];
+};
+
+__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackArgs a) {
+    const float* __restrict__ W = a.W[blockIdx.y];
+    u16* __restrict__ Wp = a.Wp[blockIdx.y];
+    const int OUT = a.OUT[blockIdx.y], IN = a.IN[blockIdx.y];
+    const int MBW = OUT / 64, KB = IN / 32;
+    const long np = (long)OUT * IN / 8;  // 16-byte pieces: one lane's fragment each (two 16-byte reads of one W row)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < np; i += (long)gridDim.x * 256) {
+        const int r = (int)(i & 15), q = (int)((i >> 4) & 3);
+        const long t = i >> 6;
+        const int mi = (int)(t % MBW), kb = (int)((t / MBW) % KB), w = (int)(t / ((long)MBW * KB));
+        const float* src = W + (size_t)(16 * (MBW * w + mi) + r) * IN + 32 * kb + 4 * q;
+        *reinterpret_cast<bf16x8*>(Wp + 8 * i) =
+            pack8<false>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 16));
+    }
+}
+
+hipError_t launch_chain_pack(const float* const* W, u16* const* Wp, const int* OUT, const int* IN, int n, hipStream_t s) {
+    ChainPackArgs a{};
+    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.Wp[k] = Wp[k]; a.OUT[k] = OUT[k]; a.IN[k] = IN[k]; }
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+#ifdef PSVAE_STAMP
+__device__ unsigned long long g_cstamp[2][8];
+#define CSTAMP(K) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[K]))
+#else
+#define CSTAMP(K) do {} while (0)
+#endif
+
+template <int KB0, int MB2, bool RECON, int RG>  // K0 = 32 KB0 inputs, NOUT = 64 MB2 outputs, 16 RG rows per tile
+__global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch batch) {
+    constexpr int TR = 16 * RG;                      // rows per tile
+    constexpr int IMG = 16 * RG * 1024;              // activation image: 16 k steps of a 512-feature activation
+    constexpr int STG = TR * SROW;
+#ifdef PSVAE_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    CSTAMP(0);
+    constexpr int HK = H / 32;                       // 16 k steps of a hidden input
+    constexpr int S = KB0 + HK + HK;                 // k steps of the weight stream
+    constexpr int NA = 3;
+    const ChainArgs& a = batch.c[blockIdx.y];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* act = reinterpret_cast<char*>(lds);        // image [16][RG][64][16 B]
+    char* stg = act + IMG;                           // staged rows
+    float* sbias = reinterpret_cast<float*>(stg + STG);  // [512 + 512 + NOUT]
+    float* stab = sbias + 2 * H + 64 * MB2;          // [7][512]: the conditional table, row 6 = 0 (label out of range)
+    float* red = stab + 7 * H;                        // [4] (no static LDS: the dynamic request is sized against the 160 KB limit)
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long tile = blockIdx.x;
+    const bool has_tab = a.ctab != nullptr;
+    // ---- weights: this wavefront's fragments, ring of three k steps -------------------------------------------------
+    auto mb_of = [&](int s) -> int { return s < KB0 + HK ? 8 : MB2; };
+    typedef const __attribute__((address_space(1))) u16 gu16;
+    typedef const __attribute__((address_space(1))) bf16x8 gbf16x8;
+    const u16* wl0 = a.wp[0] + (size_t)wave * (KB0 * 8 * 512) + lane * 8;
+    const u16* wl1 = a.wp[1] + (size_t)wave * (HK * 8 * 512) + lane * 8;
+    const u16* wl2 = a.wp[2] + (size_t)wave * (HK * MB2 * 512) + lane * 8;
+    bf16x8 wa[NA][8];
+    gu16* wsrc = nullptr;
+    auto wfetch = [&](int s) {  // in stream order
+        if (s == 0) wsrc = (gu16*)wl0;
+        if (s == KB0) wsrc = (gu16*)wl1;
+        if (s == KB0 + HK) wsrc = (gu16*)wl2;
+        asm volatile("" : "+v"(wsrc));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            if (mi < mb_of(s)) wa[s % NA][mi] = *(gbf16x8*)(wsrc + mi * 512);
+        wsrc += mb_of(s) * 512;
+    };
+    bf16x8 bb[2][RG];
+    auto bfetch = [&](int set, int kb) {
+        const char* src = act + kb * (RG * 1024) + lane * 16;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
+    };
+    wfetch(0);
+    wfetch(1);
+
+    // ---- prologue: every global read goes out before the first one is consumed (one memory round trip, not five) -----
+    constexpr int NOUT = 64 * MB2;
+    constexpr int OROW = NOUT * 4 + 16;                  // staged fp32 output row
+    constexpr int RPP = OROW * TR <= STG ? TR : TR / 2;  // output rows per staging pass (NOUT = 512: two passes of 32 rows)
+    static_assert(OROW * RPP <= STG, "staging buffer too small for the output rows");
+    constexpr int PPR = NOUT * 4 / 16;                   // 16-byte pieces per output row
+    constexpr int NPC = (RPP * PPR + 255) / 256;         // pieces per thread and pass
+    // decoder: the target rows, piece by piece as the output pass walks them -- requested FIRST: loads return in order, so
+    // anything requested after an HBM read waits for it; up front that wait coincides with the input rows'
+    f32x4 tv[RECON ? (TR / RPP) * NPC : 1];
+    if (RECON) {
+#pragma unroll
+        for (int ps = 0; ps < TR / RPP; ++ps)
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int pc = 256 * i + tid;
+                long row = tile * TR + ps * RPP + pc / PPR;
+                row = row < a.B ? row : a.B - 1;
+                tv[ps * NPC + i] = *reinterpret_cast<const f32x4*>(a.target + (size_t)row * NOUT + (pc % PPR) * 4);
+            }
+    }
+    int tg[RG], ta[RG];                                  // table rows of this lane's rows (one per row group)
+    if (has_tab) {
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            long row = tile * TR + 16 * g + r;
+            row = row < a.B ? row : a.B - 1;
+            tg[g] = a.gender[row];
+            ta[g] = a.age[row];
+        }
+    }
+    // input rows: the tile's RG x KB0 (row group, k step) pieces are dealt over the four wavefronts
+    constexpr int NIN = (RG * KB0 + 3) / 4;
+    f32x4 vin[NIN][2];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
+        if (pc < RG * KB0) {
+            long row = tile * TR + 16 * g + r;
+            row = row < a.B ? row : a.B - 1;
+            const float* ip = a.in + row * a.K0 + 32 * kb + 4 * q;
+            vin[i][0] = *reinterpret_cast<const f32x4*>(ip);
+            vin[i][1] = *reinterpret_cast<const f32x4*>(ip + 16);
+        }
+    }
+    const f32x4 vb01 = *reinterpret_cast<const f32x4*>((tid < 128 ? a.bias[0] : a.bias[1] - H) + 4 * tid);
+    f32x4 vb2 = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 16 * MB2) vb2 = *reinterpret_cast<const f32x4*>(a.bias[2] + 4 * tid);
+    f32x4 vt[3];
+    if (has_tab) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vt[i] = *reinterpret_cast<const f32x4*>(a.ctab + 4 * (tid + 256 * i));
+    }
+    *reinterpret_cast<f32x4*>(sbias + 4 * tid) = vb01;   // [bias0 | bias1]
+    if (tid < 16 * MB2) *reinterpret_cast<f32x4*>(sbias + 2 * H + 4 * tid) = vb2;
+    if (has_tab) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(stab + 4 * (tid + 256 * i)) = vt[i];
+        if (tid < 128) *reinterpret_cast<f32x4*>(stab + 6 * H + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            tg[g] = ((unsigned)tg[g] < 3u ? tg[g] : 6) * H;
+            ta[g] = ((unsigned)ta[g] < 3u ? 3 + ta[g] : 6) * H;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
+        if (pc < RG * KB0) *reinterpret_cast<bf16x8*>(act + (kb * RG + g) * 1024 + lane * 16) = pack8<false>(vin[i][0], vin[i][1]);
+    }
+    __syncthreads();
+
+    f32x4 acc[8][RG];
+    int s = 0;
+    // one layer: KB k steps over MB blocks x RG row groups; the first step's C operand is the bias (+ table rows: layer 0
+    // of a conditional chain starts from acc = bias + table[gender] + table[3 + age], summed in fp32)
+    auto layer = [&](auto KBc, auto MBc, const float* bias, bool tab) {
+        constexpr int KB = decltype(KBc)::value, MB = decltype(MBc)::value;
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (MB * wave + mi) + 4 * q);
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                acc[mi][g] = bv;
+                if (tab) {
+                    acc[mi][g] += *reinterpret_cast<const f32x4*>(stab + tg[g] + 16 * (MB * wave + mi) + 4 * q);
+                    acc[mi][g] += *reinterpret_cast<const f32x4*>(stab + ta[g] + 16 * (MB * wave + mi) + 4 * q);
+                }
+            }
+        }
+        bfetch(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb, ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < S) wfetch(s + 2);
+            if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    acc[mi][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % NA][mi], bb[kb & 1][g], acc[mi][g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // a hidden activation: (+ table rows,) ReLU, bf16 -> the next layer's image AND the staged row-major copy, which then
+    // leaves as whole rows (1 KB per store instruction) into save[]
+    auto publish = [&](u16* save) {
+        __syncthreads();  // every wavefront has read the previous image; the previous staged rows have left
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 t[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) t[g] = pack8<true>(acc[2 * kk][g], acc[2 * kk + 1][g]);
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                *reinterpret_cast<bf16x8*>(act + ((4 * wave + kk) * RG + g) * 1024 + lane * 16) = t[g];
+                // row-major: features 32 kb + 4q .. +3 and 32 kb + 16 + 4q .. +3 of row 16 g + r  (kb = 4 wave + kk)
+                char* sp = stg + (16 * g + r) * SROW + (32 * (4 * wave + kk) + 4 * q) * 2;
+                const bf16x4 lo4 = {t[g][0], t[g][1], t[g][2], t[g][3]}, hi4 = {t[g][4], t[g][5], t[g][6], t[g][7]};
+                *reinterpret_cast<bf16x4*>(sp) = lo4;
+                *reinterpret_cast<bf16x4*>(sp + 32) = hi4;
+            }
+        }
+        __syncthreads();
+        // copy-out: wavefront w sends rows 4 RG w .. 4 RG (w + 1) - 1, one 1 KB row per instruction
+        constexpr int RW = 4 * RG;
+#pragma unroll
+        for (int i0 = 0; i0 < RW; i0 += 8) {
+            bf16x8 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long row = tile * TR + RW * wave + i0 + i;
+                if (row < a.B) *reinterpret_cast<bf16x8*>(save + row * H + lane * 8) = v[i];
+            }
+        }
+    };
+    CSTAMP(1);
+    layer(std::integral_constant<int, KB0>{}, std::integral_constant<int, 8>{}, sbias, has_tab);
+    CSTAMP(2);
+    publish(a.save[0]);
+    CSTAMP(3);
+    layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{}, sbias + H, false);
+    CSTAMP(4);
+    publish(a.save[1]);
+    CSTAMP(5);
+    layer(std::integral_constant<int, HK>{}, std::integral_constant<int, MB2>{}, sbias + 2 * H, false);
+    CSTAMP(6);
+
+    // ---- output: fp32 rows through the staging buffer (the bf16 rows of save[1] have been read: barrier first) -------
+    float sq = 0.f;
+    const float gsc = RECON ? a.scale * (a.go ? *a.go : 1.0f) : 0.f;
+#pragma unroll
+    for (int ps = 0; ps < TR / RPP; ++ps) {
+        __syncthreads();
+#pragma unroll
+        for (int g = ps * (RPP / 16); g < (ps + 1) * (RPP / 16); ++g)
+#pragma unroll
+            for (int mi = 0; mi < MB2; ++mi)
+                *reinterpret_cast<f32x4*>(stg + (16 * (g - ps * (RPP / 16)) + r) * OROW + (16 * (MB2 * wave + mi) + 4 * q) * 4) = acc[mi][g];
+        __syncthreads();
+        // pieces of RPP rows, row-major: thread t takes pieces t, t + 256, ...
+#pragma unroll
+        for (int i0 = 0; i0 < NPC; i0 += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pc = 256 * (i0 + i) + tid;
+                if (i0 + i < NPC && pc < RPP * PPR) v[i] = *reinterpret_cast<const f32x4*>(stg + (pc / PPR) * OROW + (pc % PPR) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pc = 256 * (i0 + i) + tid;
+                if (i0 + i >= NPC || pc >= RPP * PPR) continue;
+                const long row = tile * TR + ps * RPP + pc / PPR;
+                if (row >= a.B) continue;
+                const size_t off = (size_t)row * NOUT + (pc % PPR) * 4;
+                *reinterpret_cast<f32x4*>(a.out + off) = v[i];
+                if (RECON) {
+                    const f32x4 xt = tv[ps * NPC + i0 + i];
+                    bf16x4 gq;
+                    float df[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        df[e] = v[i][e] - xt[e];
+                        sq += df[e] * df[e];
+                    }
+                    const nbf16x2 g0 = __builtin_convertvector(f32x2{gsc * df[0], gsc * df[1]}, nbf16x2);
+                    const nbf16x2 g1 = __builtin_convertvector(f32x2{gsc * df[2], gsc * df[3]}, nbf16x2);
+                    const s16x2 s0 = *reinterpret_cast<const s16x2*>(&g0), s1 = *reinterpret_cast<const s16x2*>(&g1);
+                    gq[0] = s0[0]; gq[1] = s0[1]; gq[2] = s1[0]; gq[3] = s1[1];
+                    *reinterpret_cast<bf16x4*>(a.gy + off) = gq;
+                }
+            }
+        }
+    }
+    if (RECON) {
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sq += __shfl_xor(sq, o2);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) a.partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    CSTAMP(7);
+#ifdef PSVAE_STAMP
+    if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 0)
+        for (int i = 0; i < 8; ++i) g_cstamp[RECON][i] = st_[i];
+#endif
+}
+
+bool chain_fwd_ok(int B, int K0, int NOUT) {
+    if (getenv("PSVAE_BF16_NO_CHAIN")) return false;
+    const int minb = getenv("PSVAE_BF16_CHAIN_MIN") ? atoi(getenv("PSVAE_BF16_CHAIN_MIN")) : 2048;
+    // D in {128, 256, 512}, Z in {64, 128}: encoders K0 = D, NOUT = Z; decoder K0 = Z, NOUT = D
+    const bool enc = (K0 == 128 || K0 == 256 || K0 == 512) && (NOUT == 64 || NOUT == 128);
+    const bool dec = (K0 == 64 || K0 == 128) && (NOUT == 128 || NOUT == 256 || NOUT == 512);
+    return B >= minb && (enc || dec);
+}
+
+template <int KB0, int MB2, bool RECON, int RG>
+static hipError_t launch_chain_rg(const ChainBatch& b, hipStream_t s) {
+    constexpr int TR = 16 * RG;
+    constexpr size_t lds = (size_t)16 * RG * 1024 + (size_t)TR * SROW + (size_t)(2 * H + 64 * MB2 + 7 * H + 4) * sizeof(float);
+    const int ntiles = (b.c[0].B + TR - 1) / TR;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_fwd_bf16_kernel<KB0, MB2, RECON, RG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    hipLaunchKernelGGL((chain_fwd_bf16_kernel<KB0, MB2, RECON, RG>), dim3(ntiles, b.n), dim3(256), lds, s, b);
+#ifdef PSVAE_STAMP
+    {
+        unsigned long long h[2][8];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cstamp), sizeof(h)) == hipSuccess) {
+            printf("chain %s stamps (cycles): prologue | L0 | publish | L1 | publish | L2 | output:", RECON ? "decoder" : "encoder");
+            for (int i = 1; i < 8; ++i) printf(" %llu", h[RECON][i] - h[RECON][i - 1]);
+            printf("\n");
+        }
+    }
+#endif
+    return hipGetLastError();
+}
+
+// rows per tile: 64, or 32 where that fills the chip better (PSVAE_CHAIN_RG = 2 | 4 overrides)
+int chain_rows_per_tile(int B, int nchains) {
+    if (const char* e = getenv("PSVAE_CHAIN_RG")) return atoi(e) == 2 ? 32 : 64;
+    return ((B + 63) / 64) * nchains >= 256 ? 64 : 32;
+}
+
+template <int KB0, int MB2, bool RECON>
+static hipError_t launch_chain_t(const ChainBatch& b, int, hipStream_t s) {
+    return chain_rows_per_tile(b.c[0].B, b.n) == 32 ? launch_chain_rg<KB0, MB2, RECON, 2>(b, s) : launch_chain_rg<KB0, MB2, RECON, 4>(b, s);
+}
+
+// every chain of a batch has the same B, K0 and NOUT (the two encoders; or the decoder alone)
+hipError_t launch_chain_fwd_bf16(const ChainBatch& b, hipStream_t s) {
+    const ChainArgs& c = b.c[0];
+    const int ntiles = 0;
+    const bool recon = c.gy != nullptr;
+#define PSVAE_ENC(KB0, MB2) if (!recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, false>(b, ntiles, s)
+#define PSVAE_DEC(KB0, MB2) if (recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, true>(b, ntiles, s)
+    PSVAE_ENC(8, 1); PSVAE_DEC(2, 4);  // cfg3: encoders 256 -> 64, decoder 64 -> 256
+    PSVAE_ENC(4, 1); PSVAE_ENC(16, 1); PSVAE_ENC(4, 2); PSVAE_ENC(8, 2); PSVAE_ENC(16, 2);
+    PSVAE_DEC(2, 2); PSVAE_DEC(2, 8); PSVAE_DEC(4, 2); PSVAE_DEC(4, 4); PSVAE_DEC(4, 8);
+#undef PSVAE_ENC
+#undef PSVAE_DEC
+    return hipErrorInvalidValue;
+}
+
+}  // namespace psvae

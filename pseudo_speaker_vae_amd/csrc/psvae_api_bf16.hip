@@ -31,6 +31,7 @@ inline int bf_wgrad_split(int B) {
 struct BfScratch {
     // weights: row-major bf16 copies Wb[i] ([out,in]) and transposed WbT[i] ([in,out]) of the 9 matrices
     u16 *Wb[9], *WbT[9];
+    u16 *Wc[9];                                     // chain-packed copies (chain_bf16.hip) of the 9 matrices
     u16 *xb;                                        // [B,D]
     u16 *h1m, *h2m, *h1s, *h2s, *d1, *d2;           // [B,H] activations, ONE layout each
     u16 *zb;                                        // [B,Z]
@@ -68,6 +69,7 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
     for (int k = 0; k < 9; ++k) {
         s.Wb[k] = tb((size_t)wo[k] * wi[k]);
         s.WbT[k] = tb((size_t)wi[k] * wo[k]);
+        s.Wc[k] = tb((size_t)wo[k] * wi[k]);
     }
     (void)Bp;
     s.xb = tb(B * D);
@@ -146,6 +148,41 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
                                      has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
     }
+    // B >= 2048: each 3-layer MLP as ONE launch over 64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
+    const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
+    if (chain) {
+        const float* Wsrc[9];
+        for (int k = 0; k < 9; ++k) Wsrc[k] = P[2 * k];
+        RET_IF(launch_chain_pack(Wsrc, sc.Wc, wo, wi, 9, s));
+        auto mlp = [&](const float* in, int K0, int NOUT, int w0, u16* s0, u16* s1, float* out, const float* ctab) {
+            ChainArgs c{};
+            c.in = in; c.B = B; c.K0 = K0; c.NOUT = NOUT;
+            for (int l = 0; l < 3; ++l) { c.wp[l] = sc.Wc[w0 + l]; c.bias[l] = P[2 * (w0 + l) + 1]; }
+            if (ctab) { c.ctab = ctab; c.gender = cond->gender; c.age = cond->age; }
+            c.save[0] = s0; c.save[1] = s1; c.out = out;
+            return c;
+        };
+        {
+            ChainBatch cb{};
+            cb.c[0] = mlp(x, D, Z, 0, sc.h1m, sc.h2m, mu, has_cond ? cond->tab[0] : nullptr);
+            cb.c[1] = mlp(x, D, Z, 3, sc.h1s, sc.h2s, logvar, has_cond ? cond->tab[1] : nullptr);
+            cb.n = 2;
+            RET_IF(launch_chain_fwd_bf16(cb, s));
+        }
+        RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
+                                 (int64_t)B * Z, s, sc.zb));
+        if (!bwd) RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
+        {
+            ChainBatch cb{};
+            cb.c[0] = mlp(z_out, Z, D, 6, sc.d1, sc.d2, x_hat, has_cond ? cond->tab[2] : nullptr);
+            cb.c[0].target = x; cb.c[0].go = grad_loss; cb.c[0].scale = 2.0f / (10.0f * (float)B * (float)D);
+            cb.c[0].gy = sc.gy; cb.c[0].partials = sc.recon_partials;
+            cb.n = 1;
+            RET_IF(launch_chain_fwd_bf16(cb, s));
+            n_recon = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1);
+            if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
+        }
+    } else {
     auto hidden = [&](const u16* A, int K, int wk, u16* out, const float* ctab) {
         GemmDescBf d = bdesc(B, H, K, A, K, sc.Wb[wk], K);
         d.bias = P[2 * wk + 1]; d.epi = BEPI_RELU; d.Cb = out; d.ldcb = H;
@@ -199,6 +236,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
         if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
     }
+    }  // per-layer forward
     }
     if (!bwd) return 0;
     // backward: wgrad  dW[o][i] = sum_b dY[b][o] X[b][i]   (A = dY [B,out], B = X [B,in]: both batch-major, read transposed

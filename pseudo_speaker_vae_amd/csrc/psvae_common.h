@@ -286,4 +286,31 @@ bool decode_fused_bf16_ok(int64_t N, int Z, int D);
 hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
                                     unsigned short* wp, hipStream_t s);
 
+// chain_bf16.hip: a 3-layer MLP of the bf16 training pass (one encoder, or the decoder) over 64-row tiles in one launch
+struct ChainArgs {
+    const float* in;                 // [B, K0] fp32
+    int B, K0, NOUT;
+    const unsigned short* wp[3];     // chain-packed bf16 weights (launch_chain_pack)
+    const float* bias[3];
+    const float* ctab;               // nullable [6, 512]: layer-0 one-hot tables
+    const int32_t* gender;
+    const int32_t* age;
+    unsigned short* save[2];         // row-major bf16 [B, 512]: the two hidden activations
+    float* out;                      // [B, NOUT] fp32
+    const float* target;             // decoder only (gy != nullptr): x, the upstream scale, 2 / (10 B D)
+    const float* go;
+    float scale;
+    unsigned short* gy;              // [B, NOUT] bf16 MSE gradient
+    float* partials;                 // [tiles] sums of squared errors
+};
+struct ChainBatch {
+    ChainArgs c[2];
+    int n;
+};
+bool chain_fwd_ok(int B, int K0, int NOUT);
+int chain_rows_per_tile(int B, int nchains);
+hipError_t launch_chain_pack(const float* const* W, unsigned short* const* Wp, const int* OUT, const int* IN, int n,
+                             hipStream_t s);
+hipError_t launch_chain_fwd_bf16(const ChainBatch& b, hipStream_t s);
+
 }  // namespace psvae

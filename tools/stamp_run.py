@@ -1,3 +1,5 @@
+"""three eager bf16 cfg3 steps (for a -DPSVAE_STAMP variant library: PSVAE_LIB=variants/libpsvae_stamp.so; the stamped
+kernels print their per-phase cycle counts)"""
 import sys, torch
 sys.path.insert(0, ".")
 from pseudo_speaker_vae_amd.engine import TrainEngine
