@@ -55,31 +55,47 @@ constexpr int SROW = 1024 + 16;          // staged row: 512 bf16 (or 256 fp32) +
 
 // Wp[wavefront w][k step kb][block mi][lane][e] = bf16(W[16 (MBW w + mi) + r][32 kb + 16 (e / 4) + 4 q + (e % 4)]),
 // W [OUT, IN] fp32 row-major, MBW = OUT / 64; grid.y = matrix
+// T = 1: the packed matrix is W^T (the backward chains' A operand): Wp[..] = bf16(W[k slot][16 (MBW w + mi) + r]), MBW = IN / 64
 struct ChainPackArgs {
-    const float* W[9];
-    u16* Wp[9];
-    int OUT[9], IN[9];
+    const float* W[16];
+    u16* Wp[16];
+    int OUT[16], IN[16], T[16];
 };
 
 __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackArgs a) {
     const float* __restrict__ W = a.W[blockIdx.y];
     u16* __restrict__ Wp = a.Wp[blockIdx.y];
     const int OUT = a.OUT[blockIdx.y], IN = a.IN[blockIdx.y];
-    const int MBW = OUT / 64, KB = IN / 32;
-    const long np = (long)OUT * IN / 8;  // 16-byte pieces: one lane's fragment each (two 16-byte reads of one W row)
+    const bool T = a.T[blockIdx.y] != 0;
+    const int N = T ? IN : OUT, K = T ? OUT : IN;  // the packed operand is [N, K]
+    const int MBW = N / 64, KB = K / 32;
+    const long np = (long)OUT * IN / 8;  // 16-byte pieces: one lane's fragment each
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < np; i += (long)gridDim.x * 256) {
         const int r = (int)(i & 15), q = (int)((i >> 4) & 3);
         const long t = i >> 6;
         const int mi = (int)(t % MBW), kb = (int)((t / MBW) % KB), w = (int)(t / ((long)MBW * KB));
-        const float* src = W + (size_t)(16 * (MBW * w + mi) + r) * IN + 32 * kb + 4 * q;
-        *reinterpret_cast<bf16x8*>(Wp + 8 * i) =
-            pack8<false>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 16));
+        const int n = 16 * (MBW * w + mi) + r, k0 = 32 * kb + 4 * q;
+        f32x4 lo, hi;
+        if (!T) {  // two 16-byte reads of row n
+            const float* src = W + (size_t)n * IN + k0;
+            lo = *reinterpret_cast<const f32x4*>(src);
+            hi = *reinterpret_cast<const f32x4*>(src + 16);
+        } else {   // column n of W: 8 strided reads (the 16 r lanes of a fragment read 16 consecutive floats of a row)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = W[(size_t)(k0 + e) * IN + n];
+                hi[e] = W[(size_t)(k0 + 16 + e) * IN + n];
+            }
+        }
+        *reinterpret_cast<bf16x8*>(Wp + 8 * i) = pack8<false>(lo, hi);
     }
 }
 
-hipError_t launch_chain_pack(const float* const* W, u16* const* Wp, const int* OUT, const int* IN, int n, hipStream_t s) {
+hipError_t launch_chain_pack(const float* const* W, u16* const* Wp, const int* OUT, const int* IN, const int* T, int n,
+                             hipStream_t s) {
+    if (n > 16) return hipErrorInvalidValue;
     ChainPackArgs a{};
-    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.Wp[k] = Wp[k]; a.OUT[k] = OUT[k]; a.IN[k] = IN[k]; }
+    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.Wp[k] = Wp[k]; a.OUT[k] = OUT[k]; a.IN[k] = IN[k]; a.T[k] = T ? T[k] : 0; }
     hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -352,6 +368,233 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 0)
         for (int i = 0; i < 8; ++i) g_cstamp[RECON][i] = st_[i];
 #endif
+}
+
+// ---- backward chains: the input-gradient (dgrad) path of one 3-layer MLP, same organisation ---------------------------
+//   layer 0: in [B, K0] (decoder: the bf16 MSE gradient g_y; encoders: fp32 g_mu / g_logvar, rounded on load)
+//            x W_last -> 512 hidden gradients, masked by the saved activation of that layer (ReLU backward) -> save[0], image
+//   layer 1: 512 -> 512 through the middle layer's weights, masked by the first hidden activation -> save[1], image
+//   layer 2 (decoder only, MB2 > 0): 512 -> Z through decoder.0's weights: g_z, fp32
+// dX[b][i] = sum_o dY[b][o] W[o][i]: in the transposed scheme the A operand is W^T, so the weights arrive packed
+// "transposed" (chain_pack_kernel, T = 1).  The saved activations are read as 8-byte pieces straight into each lane's C
+// layout (16 rows x 32 B per instruction -- 32 KB per activation and tile, requested in the prologue with everything else).
+template <int KB0, int MB2, bool IN_BF16, int RG>
+__global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBatch batch) {
+    constexpr int TR = 16 * RG;
+    constexpr int IMG = 16 * RG * 1024;
+    constexpr int STG = TR * SROW;
+    constexpr int HK = H / 32;
+    constexpr int S = KB0 + HK + (MB2 > 0 ? HK : 0);
+    constexpr int NA = 3;
+    const ChainBwdArgs& a = batch.c[blockIdx.y];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* act = reinterpret_cast<char*>(lds);
+    char* stg = act + IMG;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long tile = blockIdx.x;
+    auto mb_of = [&](int s) -> int { return s < KB0 + HK ? 8 : MB2; };
+    typedef const __attribute__((address_space(1))) u16 gu16;
+    typedef const __attribute__((address_space(1))) bf16x8 gbf16x8;
+    const u16* wl0 = a.wp[0] + (size_t)wave * (KB0 * 8 * 512) + lane * 8;
+    const u16* wl1 = a.wp[1] + (size_t)wave * (HK * 8 * 512) + lane * 8;
+    const u16* wl2 = MB2 > 0 ? a.wp[2] + (size_t)wave * (HK * MB2 * 512) + lane * 8 : nullptr;
+    bf16x8 wa[NA][8];
+    gu16* wsrc = nullptr;
+    auto wfetch = [&](int s) {
+        if (s == 0) wsrc = (gu16*)wl0;
+        if (s == KB0) wsrc = (gu16*)wl1;
+        if (s == KB0 + HK) wsrc = (gu16*)wl2;
+        asm volatile("" : "+v"(wsrc));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            if (mi < mb_of(s)) wa[s % NA][mi] = *(gbf16x8*)(wsrc + mi * 512);
+        wsrc += mb_of(s) * 512;
+    };
+    bf16x8 bb[2][RG];
+    auto bfetch = [&](int set, int kb) {
+        const char* src = act + kb * (RG * 1024) + lane * 16;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
+    };
+    wfetch(0);
+    wfetch(1);
+    // ---- prologue: input rows and both layers' masks go out together ---------------------------------------------------
+    constexpr int NIN = (RG * KB0 + 3) / 4;
+    f32x4 vin[IN_BF16 ? 1 : NIN][2];
+    bf16x4 vib[IN_BF16 ? NIN : 1][2];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
+        if (pc < RG * KB0) {
+            long row = tile * TR + 16 * g + r;
+            row = row < a.B ? row : a.B - 1;
+            if (IN_BF16) {
+                const u16* ip = reinterpret_cast<const u16*>(a.in) + row * a.K0 + 32 * kb + 4 * q;
+                vib[i][0] = *reinterpret_cast<const bf16x4*>(ip);
+                vib[i][1] = *reinterpret_cast<const bf16x4*>(ip + 16);
+            } else {
+                const float* ip = reinterpret_cast<const float*>(a.in) + row * a.K0 + 32 * kb + 4 * q;
+                vin[i][0] = *reinterpret_cast<const f32x4*>(ip);
+                vin[i][1] = *reinterpret_cast<const f32x4*>(ip + 16);
+            }
+        }
+    }
+    // masks: this lane's features of its rows, as the accumulators hold them: [layer][kk][g][half] = 4 bf16
+    bf16x4 mk[2][4][RG][2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                long row = tile * TR + 16 * g + r;
+                row = row < a.B ? row : a.B - 1;
+                const u16* mp = a.mask[l] + row * H + 32 * (4 * wave + kk) + 4 * q;
+                mk[l][kk][g][0] = *reinterpret_cast<const bf16x4*>(mp);
+                mk[l][kk][g][1] = *reinterpret_cast<const bf16x4*>(mp + 16);
+            }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
+        if (pc < RG * KB0) {
+            bf16x8 v;
+            if (IN_BF16) v = bf16x8{vib[i][0][0], vib[i][0][1], vib[i][0][2], vib[i][0][3], vib[i][1][0], vib[i][1][1], vib[i][1][2], vib[i][1][3]};
+            else v = pack8<false>(vin[i][0], vin[i][1]);
+            *reinterpret_cast<bf16x8*>(act + (kb * RG + g) * 1024 + lane * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[8][RG];
+    int s = 0;
+    auto layer = [&](auto KBc, auto MBc) {
+        constexpr int KB = decltype(KBc)::value, MB = decltype(MBc)::value;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        bfetch(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb, ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < S) wfetch(s + 2);
+            if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    acc[mi][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % NA][mi], bb[kb & 1][g], kb == 0 ? zero : acc[mi][g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // a hidden gradient: zero where the saved activation is zero (its bf16 bits: ReLU outputs are +0 or positive), bf16
+    // -> image + staged rows -> save[]
+    auto publish = [&](u16* save, int l) {
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 t[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                union { bf16x8 v; unsigned u[4]; } p;
+                p.v = pack8<false>(acc[2 * kk][g], acc[2 * kk + 1][g]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    union { bf16x4 v; unsigned u[2]; } m;
+                    m.v = mk[l][kk][g][h];
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                        union { unsigned u; u16x2 v; s16x2 sv; } w;
+                        w.u = m.u[d];
+                        w.v = __builtin_elementwise_min(w.v, u16x2{1, 1});  // 1 where the activation was positive
+                        w.sv = s16x2{0, 0} - w.sv;                           // 0xFFFF there, 0 elsewhere
+                        p.u[2 * h + d] &= w.u;
+                    }
+                }
+                t[g] = p.v;
+            }
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                *reinterpret_cast<bf16x8*>(act + ((4 * wave + kk) * RG + g) * 1024 + lane * 16) = t[g];
+                char* sp = stg + (16 * g + r) * SROW + (32 * (4 * wave + kk) + 4 * q) * 2;
+                const bf16x4 lo4 = {t[g][0], t[g][1], t[g][2], t[g][3]}, hi4 = {t[g][4], t[g][5], t[g][6], t[g][7]};
+                *reinterpret_cast<bf16x4*>(sp) = lo4;
+                *reinterpret_cast<bf16x4*>(sp + 32) = hi4;
+            }
+        }
+        __syncthreads();
+        constexpr int RW = 4 * RG;
+#pragma unroll
+        for (int i0 = 0; i0 < RW; i0 += 8) {
+            bf16x8 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long row = tile * TR + RW * wave + i0 + i;
+                if (row < a.B) *reinterpret_cast<bf16x8*>(save + row * H + lane * 8) = v[i];
+            }
+        }
+    };
+    layer(std::integral_constant<int, KB0>{}, std::integral_constant<int, 8>{});
+    publish(a.save[0], 0);
+    layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{});
+    publish(a.save[1], 1);
+    if constexpr (MB2 > 0) {
+        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, MB2>{});
+        constexpr int NOUT = 64 * MB2;
+        constexpr int OROW = NOUT * 4 + 16;
+        static_assert(OROW * TR <= STG, "staging buffer too small for the output rows");
+        constexpr int PPR = NOUT * 4 / 16;
+        constexpr int NPC = (TR * PPR + 255) / 256;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int mi = 0; mi < MB2; ++mi)
+                *reinterpret_cast<f32x4*>(stg + (16 * g + r) * OROW + (16 * (MB2 * wave + mi) + 4 * q) * 4) = acc[mi][g];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int pc = 256 * i + tid;
+            if (pc < TR * PPR) {
+                const long row = tile * TR + pc / PPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pc / PPR) * OROW + (pc % PPR) * 16);
+                if (row < a.B) *reinterpret_cast<f32x4*>(a.out + (size_t)row * NOUT + (pc % PPR) * 4) = v;
+            }
+        }
+    }
+}
+
+template <int KB0, int MB2, bool IN_BF16, int RG>
+static hipError_t launch_chain_bwd_rg(const ChainBwdBatch& b, hipStream_t s) {
+    constexpr int TR = 16 * RG;
+    constexpr size_t lds = (size_t)16 * RG * 1024 + (size_t)TR * SROW;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    const int ntiles = (b.c[0].B + TR - 1) / TR;
+    hipLaunchKernelGGL((chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>), dim3(ntiles, b.n), dim3(256), lds, s, b);
+    return hipGetLastError();
+}
+
+// decoder chain: in = g_y bf16 [B, D] (K0 = D), third layer -> g_z [B, Z]; encoder chains: in = fp32 [B, Z], two layers
+hipError_t launch_chain_bwd_bf16(const ChainBwdBatch& b, hipStream_t s) {
+    const ChainBwdArgs& c = b.c[0];
+    const bool rg2 = chain_rows_per_tile(c.B, b.n) == 32;
+#define PSVAE_BD(KB0, MB2) if (c.in_bf16 && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) \
+        return rg2 ? launch_chain_bwd_rg<KB0, MB2, true, 2>(b, s) : launch_chain_bwd_rg<KB0, MB2, true, 4>(b, s)
+#define PSVAE_BE(KB0) if (!c.in_bf16 && c.K0 == 32 * KB0 && c.NOUT == 0) \
+        return rg2 ? launch_chain_bwd_rg<KB0, 0, false, 2>(b, s) : launch_chain_bwd_rg<KB0, 0, false, 4>(b, s)
+    PSVAE_BD(8, 1); PSVAE_BE(2);  // cfg3
+    PSVAE_BD(4, 1); PSVAE_BD(16, 1); PSVAE_BD(4, 2); PSVAE_BD(8, 2); PSVAE_BD(16, 2); PSVAE_BE(4);
+#undef PSVAE_BD
+#undef PSVAE_BE
+    return hipErrorInvalidValue;
 }
 
 bool chain_fwd_ok(int B, int K0, int NOUT) {

@@ -31,7 +31,7 @@ inline int bf_wgrad_split(int B) {
 struct BfScratch {
     // weights: row-major bf16 copies Wb[i] ([out,in]) and transposed WbT[i] ([in,out]) of the 9 matrices
     u16 *Wb[9], *WbT[9];
-    u16 *Wc[9];                                     // chain-packed copies (chain_bf16.hip) of the 9 matrices
+    u16 *Wc[9], *WcT[9];                            // chain-packed copies (chain_bf16.hip): W for the forward chains, W^T for the backward
     u16 *xb;                                        // [B,D]
     u16 *h1m, *h2m, *h1s, *h2s, *d1, *d2;           // [B,H] activations, ONE layout each
     u16 *zb;                                        // [B,Z]
@@ -70,6 +70,7 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
         s.Wb[k] = tb((size_t)wo[k] * wi[k]);
         s.WbT[k] = tb((size_t)wi[k] * wo[k]);
         s.Wc[k] = tb((size_t)wo[k] * wi[k]);
+        s.WcT[k] = tb((size_t)wo[k] * wi[k]);
     }
     (void)Bp;
     s.xb = tb(B * D);
@@ -151,9 +152,12 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     // B >= 2048: each 3-layer MLP as ONE launch over 64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
     const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
     if (chain) {
-        const float* Wsrc[9];
-        for (int k = 0; k < 9; ++k) Wsrc[k] = P[2 * k];
-        RET_IF(launch_chain_pack(Wsrc, sc.Wc, wo, wi, 9, s));
+        // one launch packs W for the forward chains and W^T (all but the two input layers) for the backward chains
+        const float* Wsrc[16]; u16* Wdst[16]; int po[16], pi[16], pt[16]; int np = 0;
+        for (int k = 0; k < 9; ++k) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.Wc[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 0; }
+        for (int k = 0; k < 9; ++k)
+            if (k != 0 && k != 3) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.WcT[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 1; }
+        RET_IF(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, s));
         auto mlp = [&](const float* in, int K0, int NOUT, int w0, u16* s0, u16* s1, float* out, const float* ctab) {
             ChainArgs c{};
             c.in = in; c.B = B; c.K0 = K0; c.NOUT = NOUT;
@@ -264,6 +268,58 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         if (act) { d.epi = BEPI_MASK; d.mask = act; d.ldmask = in_; }
         return d;
     };
+    if (chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D)) {
+        // every input gradient by two chain launches (decoder; then, behind the reparameterisation's backward, both encoders),
+        // then ALL weight gradients -- nine matrices and the three tables -- as one launch, and the slab sums
+        {
+            ChainBwdBatch cb{};
+            ChainBwdArgs& c = cb.c[0];
+            c.in = sc.gy; c.in_bf16 = 1; c.B = B; c.K0 = D; c.NOUT = Z;
+            c.wp[0] = sc.WcT[8]; c.wp[1] = sc.WcT[7]; c.wp[2] = sc.WcT[6];
+            c.mask[0] = sc.d2; c.mask[1] = sc.d1; c.save[0] = sc.dd2; c.save[1] = sc.dd1; c.out = sc.gz;
+            cb.n = 1;
+            RET_IF(launch_chain_bwd_bf16(cb, s));
+        }
+        {
+            u16* rm[2] = {sc.gmu, sc.glv};
+            RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
+                                            sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
+                                            eps_in ? nullptr : rng_state, s, rm));
+        }
+        {
+            ChainBwdBatch cb{};
+            for (int e = 0; e < 2; ++e) {
+                ChainBwdArgs& c = cb.c[e];
+                c.in = e ? sc.glv_f : sc.gmu_f; c.in_bf16 = 0; c.B = B; c.K0 = Z; c.NOUT = 0;
+                c.wp[0] = sc.WcT[e ? 5 : 2]; c.wp[1] = sc.WcT[e ? 4 : 1]; c.wp[2] = nullptr;
+                c.mask[0] = e ? sc.h2s : sc.h2m; c.mask[1] = e ? sc.h1s : sc.h1m;
+                c.save[0] = e ? sc.dh2s : sc.dh2m; c.save[1] = e ? sc.dh1s : sc.dh1m; c.out = nullptr;
+            }
+            cb.n = 2;
+            RET_IF(launch_chain_bwd_bf16(cb, s));
+        }
+        {
+            GemmBatchBf b{};
+            addb(b, wgrad(sc.gy, D, D, sc.d2, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
+            addb(b, wgrad(sc.dd2, H, H, sc.d1, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
+            addb(b, wgrad(sc.dd1, H, H, sc.zb, Z, G[12], G[13], sc.slab_w[6], sc.slab_b[6]));
+            addb(b, wgrad(sc.gmu, Z, Z, sc.h2m, H, G[4], G[5], sc.slab_w[2], sc.slab_b[2]));
+            addb(b, wgrad(sc.glv, Z, Z, sc.h2s, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
+            addb(b, wgrad(sc.dh2m, H, H, sc.h1m, H, G[2], G[3], sc.slab_w[1], sc.slab_b[1]));
+            addb(b, wgrad(sc.dh2s, H, H, sc.h1s, H, G[8], G[9], sc.slab_w[4], sc.slab_b[4]));
+            addb(b, wgrad(sc.dh1m, H, H, sc.xb, D, G[0], G[1], sc.slab_w[0], sc.slab_b[0]));
+            addb(b, wgrad(sc.dh1s, H, H, sc.xb, D, G[6], G[7], sc.slab_w[3], sc.slab_b[3]));
+            if (has_cond) {
+                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dd1, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));
+                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1m, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
+                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
+            }
+            b.force_staged = 1;
+            RET_IF(launch_gemm_batch_bf16(b, s));
+        }
+        if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
+        return 0;
+    }
     {
         GemmBatchBf b{};
         addb(b, wgrad(sc.gy, D, D, sc.d2, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));

@@ -139,8 +139,9 @@ struct GemmDescBf {
     int epi;
     int tiles_m, tiles_n, tile_begin;
 };
+constexpr int MAX_GROUP_BF = 12;  // (all nine weight gradients and the three table gradients of a pass fit one launch)
 struct GemmBatchBf {
-    GemmDescBf d[MAX_GROUP];
+    GemmDescBf d[MAX_GROUP_BF];
     int n;
     int total_tiles;
     int force_staged;  // host-side: 1 = launch with the LDS-staged 128x128 kernel whatever the tile count
@@ -309,8 +310,22 @@ struct ChainBatch {
 };
 bool chain_fwd_ok(int B, int K0, int NOUT);
 int chain_rows_per_tile(int B, int nchains);
-hipError_t launch_chain_pack(const float* const* W, unsigned short* const* Wp, const int* OUT, const int* IN, int n,
-                             hipStream_t s);
+hipError_t launch_chain_pack(const float* const* W, unsigned short* const* Wp, const int* OUT, const int* IN, const int* T,
+                             int n, hipStream_t s);
+struct ChainBwdArgs {
+    const void* in;                  // [B, K0]: bf16 row-major (in_bf16) or fp32
+    int in_bf16;
+    int B, K0, NOUT;                 // NOUT = 0: two layers only
+    const unsigned short* wp[3];     // transposed chain-packed weights
+    const unsigned short* mask[2];   // saved forward activations [B, 512] bf16 (ReLU masks of layers 0 and 1)
+    unsigned short* save[2];         // [B, 512] bf16 row-major hidden gradients
+    float* out;                      // [B, NOUT] fp32
+};
+struct ChainBwdBatch {
+    ChainBwdArgs c[2];
+    int n;
+};
+hipError_t launch_chain_bwd_bf16(const ChainBwdBatch& b, hipStream_t s);
 hipError_t launch_chain_fwd_bf16(const ChainBatch& b, hipStream_t s);
 
 }  // namespace psvae
