@@ -137,8 +137,15 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     weight_dims(D, Z, wo, wi);
 
     int n_recon = sc.n_recon_max;  // backward-only call: every slot (the forward-only call zeroed the unused ones)
+    // B >= 2048: each 3-layer MLP as ONE launch over 32/64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
+    const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
     if (fwd) {
-    {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
+    if (chain) {  // the chains read fp32 x and their own weight packs: only the weight gradients' x operand and the one-hot matrix
+        const float* src[1] = {x}; u16* dst[1] = {sc.xb}; u16* dstT[1] = {nullptr};
+        int R[1] = {B}, C[1] = {D}, ld[1] = {D}, ldt[1] = {0};
+        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 1, s, has_cond ? cond->gender : nullptr,
+                                     has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
+    } else {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
             src[k] = P[2 * k]; dst[k] = sc.Wb[k]; dstT[k] = sc.WbT[k];
@@ -149,8 +156,6 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
                                      has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
     }
-    // B >= 2048: each 3-layer MLP as ONE launch over 64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
-    const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
     if (chain) {
         // one launch packs W for the forward chains and W^T (all but the two input layers) for the backward chains
         const float* Wsrc[16]; u16* Wdst[16]; int po[16], pi[16], pt[16]; int np = 0;
@@ -246,7 +251,18 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     // backward: wgrad  dW[o][i] = sum_b dY[b][o] X[b][i]   (A = dY [B,out], B = X [B,in]: both batch-major, read transposed
     //                                                       out of the staged LDS tiles; fp32 out, colsum = db)
     //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]  (A = dY [B,out], B = W^T [in,out], masked, bf16 out)
-    const int S = bf_wgrad_split(B);
+    const bool chain_bwd = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
+    int S = bf_wgrad_split(B);
+    if (chain_bwd && !getenv("PSVAE_BF16_WGRAD_S")) {
+        // all weight gradients share ONE launch there: cut the batch so that its 128x128 tiles make two rounds of workgroups
+        // (B = 4096, conditional: 96 tiles; S = 4 / 5 / 6 / 8 measured 133.5 / 130.7 / 139.3 / 142.2 us per step)
+        int T = 0;
+        for (int k = 0; k < 9; ++k) T += ((wo[k] + 127) / 128) * ((wi[k] + 127) / 128);
+        if (has_cond) T += 3 * ((H + 127) / 128);
+        S = 512 / T;
+        S = S < 1 ? 1 : (S > BF_SMAX ? BF_SMAX : S);
+        while (S > 1 && B / S < 256) --S;  // (at least 256 batch rows per slice)
+    }
     const float* rsrc[24]; float* rdst[24]; int64_t rnum[24]; int rS[24]; int nred = 0;
     auto wgrad = [&](const u16* dY, int out_, int ldy, const u16* X, int in_, float* dW, float* db, float* slabW, float* slabB) {
         GemmDescBf d = bdesc(out_, in_, B, dY, ldy, X, in_);
@@ -268,7 +284,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         if (act) { d.epi = BEPI_MASK; d.mask = act; d.ldmask = in_; }
         return d;
     };
-    if (chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D)) {
+    if (chain_bwd) {
         // every input gradient by two chain launches (decoder; then, behind the reparameterisation's backward, both encoders),
         // then ALL weight gradients -- nine matrices and the three tables -- as one launch, and the slab sums
         {
