@@ -43,6 +43,31 @@ def tile_mode(request, monkeypatch):
 @pytest.mark.parametrize("D,Z,B,cond", [(256, 64, 4096, True), (256, 64, 1024, False), (256, 64, 100, True),
                                         (512, 128, 64, False), (256, 64, 2100, True)])
 def test_bf16_train_step_matches_emulation(D, Z, B, cond, tile_mode):
+    _check_train_step(D, Z, B, cond)
+
+
+@pytest.mark.parametrize("D,Z,B,cond,how", [
+    (256, 64, 4096, True, "chain-64"),     # 64-row tiles forced (default at this size: 32)
+    (256, 64, 4096, True, "per-layer"),    # the launch-per-layer path stays covered at the size the chains took over
+    (512, 128, 2048, False, "chain"),      # D = 512: two output staging passes; Z = 128
+    (128, 64, 2500, True, "chain"),        # ragged last tile, D = 128
+    (512, 64, 2049, True, "chain-64"),     # one row in the last 64-row tile
+    (256, 128, 3000, False, "chain"),
+    (256, 64, 300, False, "chain-forced")  # chains forced below their batch threshold: 10 tiles, the last one ragged
+])
+def test_bf16_row_chains_match_emulation(D, Z, B, cond, how, monkeypatch):
+    """B >= 2048 runs every 3-layer MLP of the pass as one chain launch per direction (csrc/chain_bf16.hip) and all weight
+    gradients as one launch; same emulation, same bounds as the per-layer path"""
+    if how == "chain-64":
+        monkeypatch.setenv("PSVAE_CHAIN_RG", "4")
+    if how == "per-layer":
+        monkeypatch.setenv("PSVAE_BF16_NO_CHAIN", "1")
+    if how == "chain-forced":
+        monkeypatch.setenv("PSVAE_BF16_CHAIN_MIN", "1")
+    _check_train_step(D, Z, B, cond)
+
+
+def _check_train_step(D, Z, B, cond):
     from pseudo_speaker_vae_amd import _ffi, ops
     p = O.init_params(D, Z, 1)
     torch.manual_seed(B)
