@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "psvae_common.h"
+#include "psvae_device.h"
 
 namespace psvae {
 
@@ -60,9 +61,37 @@ struct ChainPackArgs {
     const float* W[16];
     u16* Wp[16];
     int OUT[16], IN[16], T[16];
+    int n;
+    // riders (grid.y = n, n + 1): x -> bf16 row-major (the weight gradients' operand) and the one-hot label matrix [B][8]
+    const float* x;
+    u16* xb;
+    long nx;
+    const int32_t* gender;
+    const int32_t* age;
+    u16* oh;
+    int B;
 };
 
 __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackArgs a) {
+    if ((int)blockIdx.y == a.n) {  // x cast, 8 elements per thread and step
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < a.nx; i += (long)gridDim.x * 256 * 8)
+            *reinterpret_cast<bf16x8*>(a.xb + i) =
+                pack8<false>(*reinterpret_cast<const f32x4*>(a.x + i), *reinterpret_cast<const f32x4*>(a.x + i + 4));
+        return;
+    }
+    if ((int)blockIdx.y == a.n + 1) {
+        for (int b = blockIdx.x * 256 + threadIdx.x; b < a.B; b += gridDim.x * 256) {
+            const int g = a.gender[b], ag = a.age[b];
+            bf16x8 row = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                row[c] = (g == c) ? (short)0x3F80 : (short)0;
+                row[3 + c] = (ag == c) ? (short)0x3F80 : (short)0;
+            }
+            *reinterpret_cast<bf16x8*>(a.oh + (size_t)b * 8) = row;
+        }
+        return;
+    }
     const float* __restrict__ W = a.W[blockIdx.y];
     u16* __restrict__ Wp = a.Wp[blockIdx.y];
     const int OUT = a.OUT[blockIdx.y], IN = a.IN[blockIdx.y];
@@ -92,11 +121,13 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackArgs a) 
 }
 
 hipError_t launch_chain_pack(const float* const* W, u16* const* Wp, const int* OUT, const int* IN, const int* T, int n,
+                             const float* x, u16* xb, long nx, const int32_t* gender, const int32_t* age, u16* oh, int B,
                              hipStream_t s) {
-    if (n > 16) return hipErrorInvalidValue;
+    if (n > 16 || (nx & 7)) return hipErrorInvalidValue;
     ChainPackArgs a{};
     for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.Wp[k] = Wp[k]; a.OUT[k] = OUT[k]; a.IN[k] = IN[k]; a.T[k] = T ? T[k] : 0; }
-    hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n), dim3(256), 0, s, a);
+    a.n = n; a.x = x; a.xb = xb; a.nx = nx; a.gender = gender; a.age = age; a.oh = oh; a.B = B;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n + 1 + (oh ? 1 : 0)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -189,18 +220,30 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             ta[g] = a.age[row];
         }
     }
-    // input rows: the tile's RG x KB0 (row group, k step) pieces are dealt over the four wavefronts
+    // input rows: the tile's RG x KB0 (row group, k step) pieces are dealt over the four wavefronts.  The decoder chain of
+    // a training pass builds its input itself: z = mu + exp(log sigma^2 / 2) eps (model.py:56-57) with eps given or drawn
+    // (Philox block = flat element index / 4, as reparam_kl_kernel), and leaves eps, z (fp32 and bf16) and the tile's KL sum
     constexpr int NIN = (RG * KB0 + 3) / 4;
-    f32x4 vin[NIN][2];
+    const bool rep = RECON && a.mu != nullptr;  // (decoder instantiations only: the encoders carry none of this)
+    f32x4 vin[NIN][2], vlv[NIN][2], vep[NIN][2];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
         if (pc < RG * KB0) {
             long row = tile * TR + 16 * g + r;
             row = row < a.B ? row : a.B - 1;
-            const float* ip = a.in + row * a.K0 + 32 * kb + 4 * q;
+            const size_t off = (size_t)row * a.K0 + 32 * kb + 4 * q;
+            const float* ip = (rep ? a.mu : a.in) + off;
             vin[i][0] = *reinterpret_cast<const f32x4*>(ip);
             vin[i][1] = *reinterpret_cast<const f32x4*>(ip + 16);
+            if (rep) {
+                vlv[i][0] = *reinterpret_cast<const f32x4*>(a.lv + off);
+                vlv[i][1] = *reinterpret_cast<const f32x4*>(a.lv + off + 16);
+                if (a.eps_in) {
+                    vep[i][0] = *reinterpret_cast<const f32x4*>(a.eps_in + off);
+                    vep[i][1] = *reinterpret_cast<const f32x4*>(a.eps_in + off + 16);
+                }
+            }
         }
     }
     const f32x4 vb01 = *reinterpret_cast<const f32x4*>((tid < 128 ? a.bias[0] : a.bias[1] - H) + 4 * tid);
@@ -223,12 +266,46 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             ta[g] = ((unsigned)ta[g] < 3u ? 3 + ta[g] : 6) * H;
         }
     }
+    float kl = 0.f;
+    if (rep) {
+        uint64_t seed = a.seed, offset = a.offset;
+        if (a.rng && !a.eps_in) { seed = a.rng[0]; offset = a.rng[1]; }
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
+            const long row = tile * TR + 16 * g + r;
+            if (pc < RG * KB0 && row < a.B) {
+                const size_t off = (size_t)row * a.K0 + 32 * kb + 4 * q;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 ep = a.eps_in ? vep[i][h] : philox_normal4(offset + (uint64_t)((off + 16 * h) >> 2), seed);
+                    const f32x4 m = vin[i][h], l = vlv[i][h];
+                    f32x4 zz;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        zz[e] = m[e] + expf(0.5f * l[e]) * ep[e];
+                        kl += 1.0f + l[e] - m[e] * m[e] - expf(l[e]);
+                    }
+                    vin[i][h] = zz;
+                    *reinterpret_cast<f32x4*>(a.eps_out + off + 16 * h) = ep;
+                    *reinterpret_cast<f32x4*>(a.z_out + off + 16 * h) = zz;
+                }
+                const bf16x8 zp = pack8<false>(vin[i][0], vin[i][1]);
+                *reinterpret_cast<bf16x4*>(a.zb + off) = bf16x4{zp[0], zp[1], zp[2], zp[3]};
+                *reinterpret_cast<bf16x4*>(a.zb + off + 16) = bf16x4{zp[4], zp[5], zp[6], zp[7]};
+            }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) kl += __shfl_xor(kl, o2);
+        if (lane == 0) red[wave] = kl;
+    }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
         if (pc < RG * KB0) *reinterpret_cast<bf16x8*>(act + (kb * RG + g) * 1024 + lane * 16) = pack8<false>(vin[i][0], vin[i][1]);
     }
     __syncthreads();
+    if (rep && tid == 0) a.kl_partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
 
     f32x4 acc[8][RG];
     int s = 0;
@@ -554,13 +631,54 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
             for (int mi = 0; mi < MB2; ++mi)
                 *reinterpret_cast<f32x4*>(stg + (16 * g + r) * OROW + (16 * (MB2 * wave + mi) + 4 * q) * 4) = acc[mi][g];
         __syncthreads();
+        // g_z leaves as whole rows; a training pass turns it into g_mu / g_logvar on the way out (the reparameterisation's
+        // backward plus the KL term's gradient, lightning.py:115-120 through autograd; reparam_bwd_final_kernel's formulas)
+        const bool rb = a.mu != nullptr;
+        const float kbeta = rb ? (a.go ? *a.go : 1.0f) * a.beta / (float)a.B : 0.f;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int pc = 256 * i + tid;
             if (pc < TR * PPR) {
                 const long row = tile * TR + pc / PPR;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pc / PPR) * OROW + (pc % PPR) * 16);
-                if (row < a.B) *reinterpret_cast<f32x4*>(a.out + (size_t)row * NOUT + (pc % PPR) * 4) = v;
+                if (row < a.B) {
+                    const size_t off = (size_t)row * NOUT + (pc % PPR) * 4;
+                    if (!rb) {
+                        *reinterpret_cast<f32x4*>(a.out + off) = v;
+                    } else {
+                        const f32x4 m = *reinterpret_cast<const f32x4*>(a.mu + off), l = *reinterpret_cast<const f32x4*>(a.lv + off);
+                        const f32x4 ep = *reinterpret_cast<const f32x4*>(a.eps + off);
+                        f32x4 gm, gl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gm[e] = v[e] + kbeta * m[e];
+                            gl[e] = v[e] * ep[e] * 0.5f * expf(0.5f * l[e]) + 0.5f * kbeta * (expf(l[e]) - 1.0f);
+                        }
+                        *reinterpret_cast<f32x4*>(a.g_mu + off) = gm;
+                        *reinterpret_cast<f32x4*>(a.g_lv + off) = gl;
+                        const bf16x8 pk = pack8<false>(gm, gl);
+                        *reinterpret_cast<bf16x4*>(a.gmu_b + off) = bf16x4{pk[0], pk[1], pk[2], pk[3]};
+                        *reinterpret_cast<bf16x4*>(a.glv_b + off) = bf16x4{pk[4], pk[5], pk[6], pk[7]};
+                    }
+                }
+            }
+        }
+        if (rb && tile == 0) {  // the loss from the forward's partial sums, and the Philox state's advance (every reader ran
+            float* sh4 = reinterpret_cast<float*>(stg);  // launches ago); `stg` is free once every thread's reads above are done
+            __syncthreads();
+            float k = 0.f, rr = 0.f;
+            for (int i = tid; i < a.n_kl; i += 256) k += a.kl_partials[i];
+            for (int i = tid; i < a.n_recon; i += 256) rr += a.recon_partials[i];
+            const float ks = block_sum_256(k, sh4);
+            __syncthreads();
+            const float rs = block_sum_256(rr, sh4);
+            if (tid == 0) {
+                const float recon = rs / ((float)a.B * (float)a.K0) / 10.0f;
+                const float klv = -0.5f * ks / (float)a.B;
+                a.loss3[0] = recon + a.beta * klv;
+                a.loss3[1] = recon;
+                a.loss3[2] = klv;
+                if (a.rng) a.rng[1] += a.nblk;
             }
         }
     }

@@ -140,11 +140,8 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     // B >= 2048: each 3-layer MLP as ONE launch over 32/64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
     const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
     if (fwd) {
-    if (chain) {  // the chains read fp32 x and their own weight packs: only the weight gradients' x operand and the one-hot matrix
-        const float* src[1] = {x}; u16* dst[1] = {sc.xb}; u16* dstT[1] = {nullptr};
-        int R[1] = {B}, C[1] = {D}, ld[1] = {D}, ldt[1] = {0};
-        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 1, s, has_cond ? cond->gender : nullptr,
-                                     has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
+    if (chain) {  // (the chains read fp32 x and their own weight packs; x -> bf16 and the one-hot matrix, which only the weight
+                  //  gradients read, ride the pack launch below)
     } else {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
@@ -162,7 +159,8 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         for (int k = 0; k < 9; ++k) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.Wc[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 0; }
         for (int k = 0; k < 9; ++k)
             if (k != 0 && k != 3) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.WcT[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 1; }
-        RET_IF(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, s));
+        RET_IF(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, x, sc.xb, (long)B * D, has_cond ? cond->gender : nullptr,
+                                 has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B, s));
         auto mlp = [&](const float* in, int K0, int NOUT, int w0, u16* s0, u16* s1, float* out, const float* ctab) {
             ChainArgs c{};
             c.in = in; c.B = B; c.K0 = K0; c.NOUT = NOUT;
@@ -178,12 +176,13 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             cb.n = 2;
             RET_IF(launch_chain_fwd_bf16(cb, s));
         }
-        RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
-                                 (int64_t)B * Z, s, sc.zb));
         if (!bwd) RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
-        {
+        {   // decoder chain; its input stage is the reparameterisation (eps, z, z in bf16, KL partial per tile)
             ChainBatch cb{};
-            cb.c[0] = mlp(z_out, Z, D, 6, sc.d1, sc.d2, x_hat, has_cond ? cond->tab[2] : nullptr);
+            cb.c[0] = mlp(nullptr, Z, D, 6, sc.d1, sc.d2, x_hat, has_cond ? cond->tab[2] : nullptr);
+            cb.c[0].mu = mu; cb.c[0].lv = logvar; cb.c[0].eps_in = eps_in; cb.c[0].rng = eps_in ? nullptr : rng_state;
+            cb.c[0].seed = seed; cb.c[0].offset = offset; cb.c[0].eps_out = eps_out; cb.c[0].z_out = z_out; cb.c[0].zb = sc.zb;
+            cb.c[0].kl_partials = sc.kl_partials;
             cb.c[0].target = x; cb.c[0].go = grad_loss; cb.c[0].scale = 2.0f / (10.0f * (float)B * (float)D);
             cb.c[0].gy = sc.gy; cb.c[0].partials = sc.recon_partials;
             cb.n = 1;
@@ -292,15 +291,15 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             ChainBwdArgs& c = cb.c[0];
             c.in = sc.gy; c.in_bf16 = 1; c.B = B; c.K0 = D; c.NOUT = Z;
             c.wp[0] = sc.WcT[8]; c.wp[1] = sc.WcT[7]; c.wp[2] = sc.WcT[6];
-            c.mask[0] = sc.d2; c.mask[1] = sc.d1; c.save[0] = sc.dd2; c.save[1] = sc.dd1; c.out = sc.gz;
+            c.mask[0] = sc.d2; c.mask[1] = sc.d1; c.save[0] = sc.dd2; c.save[1] = sc.dd1; c.out = nullptr;
+            // g_z -> g_mu, g_logvar (fp32 for the encoder chains, bf16 for the heads' weight gradients), loss, Philox advance
+            c.mu = mu; c.lv = logvar; c.eps = eps_out; c.go = grad_loss; c.beta = beta;
+            c.g_mu = sc.gmu_f; c.g_lv = sc.glv_f; c.gmu_b = sc.gmu; c.glv_b = sc.glv;
+            c.kl_partials = sc.kl_partials; c.recon_partials = sc.recon_partials;
+            c.n_kl = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1); c.n_recon = n_recon;
+            c.loss3 = loss3; c.rng = eps_in ? nullptr : rng_state; c.nblk = (uint64_t)(((int64_t)B * Z + 3) / 4);
             cb.n = 1;
             RET_IF(launch_chain_bwd_bf16(cb, s));
-        }
-        {
-            u16* rm[2] = {sc.gmu, sc.glv};
-            RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
-                                            sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
-                                            eps_in ? nullptr : rng_state, s, rm));
         }
         {
             ChainBwdBatch cb{};

@@ -303,6 +303,16 @@ struct ChainArgs {
     float scale;
     unsigned short* gy;              // [B, NOUT] bf16 MSE gradient
     float* partials;                 // [tiles] sums of squared errors
+    // decoder of a training pass (mu != nullptr): the input is z = mu + exp(lv / 2) eps, built in the kernel (`in` unused)
+    const float* mu;
+    const float* lv;
+    const float* eps_in;             // nullable: draw with Philox (rng {seed, offset} on the device if given, else seed / offset)
+    const uint64_t* rng;
+    uint64_t seed, offset;
+    float* eps_out;                  // [B, K0] fp32
+    float* z_out;                    // [B, K0] fp32
+    unsigned short* zb;              // [B, K0] bf16
+    float* kl_partials;              // [tiles]: sum of 1 + lv - mu^2 - exp(lv)
 };
 struct ChainBatch {
     ChainArgs c[2];
@@ -311,7 +321,8 @@ struct ChainBatch {
 bool chain_fwd_ok(int B, int K0, int NOUT);
 int chain_rows_per_tile(int B, int nchains);
 hipError_t launch_chain_pack(const float* const* W, unsigned short* const* Wp, const int* OUT, const int* IN, const int* T,
-                             int n, hipStream_t s);
+                             int n, const float* x, unsigned short* xb, long nx, const int32_t* gender, const int32_t* age,
+                             unsigned short* oh, int B, hipStream_t s);
 struct ChainBwdArgs {
     const void* in;                  // [B, K0]: bf16 row-major (in_bf16) or fp32
     int in_bf16;
@@ -319,7 +330,24 @@ struct ChainBwdArgs {
     const unsigned short* wp[3];     // transposed chain-packed weights
     const unsigned short* mask[2];   // saved forward activations [B, 512] bf16 (ReLU masks of layers 0 and 1)
     unsigned short* save[2];         // [B, 512] bf16 row-major hidden gradients
-    float* out;                      // [B, NOUT] fp32
+    float* out;                      // [B, NOUT] fp32 (plain third-layer output; unused when mu != nullptr)
+    // decoder of a training pass (mu != nullptr): the third layer's g_z becomes g_mu / g_logvar on the way out, and tile 0
+    // finishes the loss and advances the Philox state
+    const float* mu;
+    const float* lv;
+    const float* eps;
+    const float* go;                 // nullable device scalar
+    float beta;
+    float* g_mu;                     // [B, NOUT] fp32
+    float* g_lv;
+    unsigned short* gmu_b;           // [B, NOUT] bf16
+    unsigned short* glv_b;
+    const float* kl_partials;
+    const float* recon_partials;
+    int n_kl, n_recon;
+    float* loss3;
+    uint64_t* rng;                   // nullable
+    uint64_t nblk;
 };
 struct ChainBwdBatch {
     ChainBwdArgs c[2];
