@@ -531,6 +531,22 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
                 mk[l][kk][g][0] = *reinterpret_cast<const bf16x4*>(mp);
                 mk[l][kk][g][1] = *reinterpret_cast<const bf16x4*>(mp + 16);
             }
+    // training pass: the rows of mu, log sigma^2 and eps the output pass will need, piece by piece as it walks them
+    constexpr int NPCR = MB2 > 0 ? (TR * (64 * MB2 * 4 / 16) + 255) / 256 : 1;
+    f32x4 rmu[NPCR], rlv[NPCR], rep_[NPCR];
+    if (MB2 > 0 && a.mu != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NPCR; ++i) {
+            constexpr int PPR_ = MB2 > 0 ? 64 * MB2 * 4 / 16 : 1;
+            const int pc = 256 * i + tid;
+            long row = tile * TR + pc / PPR_;
+            row = row < a.B ? row : a.B - 1;
+            const size_t off = (size_t)row * (64 * MB2) + (pc % PPR_) * 4;
+            rmu[i] = *reinterpret_cast<const f32x4*>(a.mu + off);
+            rlv[i] = *reinterpret_cast<const f32x4*>(a.lv + off);
+            rep_[i] = *reinterpret_cast<const f32x4*>(a.eps + off);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
@@ -646,8 +662,7 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
                     if (!rb) {
                         *reinterpret_cast<f32x4*>(a.out + off) = v;
                     } else {
-                        const f32x4 m = *reinterpret_cast<const f32x4*>(a.mu + off), l = *reinterpret_cast<const f32x4*>(a.lv + off);
-                        const f32x4 ep = *reinterpret_cast<const f32x4*>(a.eps + off);
+                        const f32x4 m = rmu[i], l = rlv[i], ep = rep_[i];
                         f32x4 gm, gl;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
