@@ -31,7 +31,8 @@ def assert_close_bf16(a, b, what):
 def tile_mode(request, monkeypatch):
     """the 128x128 LDS-staged kernel normally starts at >= 2048 64x64 tiles; force it for forward / dgrad-only
     launches so the parity cases below cover both main loops (PSVAE_BF16_BIG_MIN is read per launch)"""
-    if request.param == "lds-staged-128x128":
+    monkeypatch.setenv("PSVAE_BF16_NO_CHAIN", "1")  # these four modes are the launch-per-layer path's (the row chains, the
+    if request.param == "lds-staged-128x128":         # default from B = 64 up, have their own cases below)
         monkeypatch.setenv("PSVAE_BF16_BIG_MIN", "1")
     if request.param == "split-wgrad-3":  # the large-batch backward (weight gradients cut over 3 workgroups per tile,
         monkeypatch.setenv("PSVAE_BF16_WGRAD_S", "3")  # some slices empty at small B) forced at every size
@@ -53,7 +54,10 @@ def test_bf16_train_step_matches_emulation(D, Z, B, cond, tile_mode):
     (128, 64, 2500, True, "chain"),        # ragged last tile, D = 128
     (512, 64, 2049, True, "chain-64"),     # one row in the last 64-row tile
     (256, 128, 3000, False, "chain"),
-    (256, 64, 300, False, "chain-forced")  # chains forced below their batch threshold: 10 tiles, the last one ragged
+    (256, 64, 300, False, "chain"),        # 10 tiles, the last one ragged
+    (256, 64, 100, True, "chain"),
+    (256, 64, 1024, False, "chain"),
+    (256, 64, 40, False, "chain-forced"),  # below the chains' batch threshold (64): two tiles, 8 valid rows in the second
 ])
 def test_bf16_row_chains_match_emulation(D, Z, B, cond, how, monkeypatch):
     """B >= 2048 runs every 3-layer MLP of the pass as one chain launch per direction (csrc/chain_bf16.hip) and all weight
