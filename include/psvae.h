@@ -191,7 +191,10 @@ int psvae_set_plan(const psvae_dims* dims, const char* text);
  * weights, gradients and loss).  D and Z must be multiples of 32.  x, params, grads, outputs, eps_out[B,Z] and
  * z_out[B,Z] are fp32; all bf16 intermediates live in `scratch` (psvae_bf16_scratch_bytes).  Activations and
  * gradients exist in ONE bf16 layout: the weight gradients read their batch-major operands transposed out of LDS
- * (ds_read_b64_tr_b16).  cond (nullable) adds the one-hot gather tables. */
+ * (ds_read_b64_tr_b16).  cond (nullable) adds the one-hot gather tables.
+ * From B = 64 up, with D in {128, 256, 512} and Z in {64, 128}, the pass runs as 7 launches: every 3-layer MLP (each
+ * encoder, the decoder) is one "row chain" launch per direction with its activations in LDS, and all weight gradients are
+ * one launch (csrc/chain_bf16.hip); other shapes take a launch per layer. */
 size_t psvae_bf16_scratch_bytes(const psvae_dims* dims);
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params,
                           const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,
