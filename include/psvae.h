@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 2
+#define PSVAE_ABI_VERSION 3
 #define PSVAE_HIDDEN 512
 #define PSVAE_NPARAM 18
 #define PSVAE_COND_DIM 6 /* onehot3(gender) || onehot3(age), SURVEY.md section 8a row A9 */
@@ -194,14 +194,17 @@ int psvae_set_plan(const psvae_dims* dims, const char* text);
  * (ds_read_b64_tr_b16).  cond (nullable) adds the one-hot gather tables.
  * From B = 64 up, with D in {128, 256, 512} and Z in {64, 128}, the pass runs as 7 launches: every 3-layer MLP (each
  * encoder, the decoder) is one "row chain" launch per direction with its activations in LDS, and all weight gradients are
- * one launch (csrc/chain_bf16.hip); other shapes take a launch per layer. */
+ * one launch (csrc/chain_bf16.hip); other shapes take a launch per layer.
+ * flags: the loss variants of the fp32 step (L2-normalised decoder output, model.py:60-61; cosine loss, lightning.py:110-111),
+ * available on the row-chain shapes (PSVAE_ERR_SHAPE elsewhere): the decoder chain leaves the raw output and one row kernel
+ * normalises, takes the loss term and the gradient w.r.t. the raw output. */
 size_t psvae_bf16_scratch_bytes(const psvae_dims* dims);
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params,
                           const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,
                           uint64_t seed, uint64_t offset, uint64_t* rng_state /* nullable */, float* eps_out,
                           float* z_out, float* x_hat, float* mu, float* logvar, float beta,
                           const float* grad_loss /* nullable = 1 */, const psvae_grads* grads, float* loss3,
-                          void* scratch, void* stream);
+                          void* scratch, uint32_t flags /* PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS */, void* stream);
 
 /* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
  * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
@@ -247,11 +250,11 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
 int psvae_forward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                        const float* eps_in, uint64_t seed, uint64_t offset, const uint64_t* rng_state, float* eps_out,
                        float* z_out, float* x_hat, float* mu, float* logvar, const float* grad_loss, void* scratch,
-                       void* stream);
+                       uint32_t flags, void* stream);
 int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                         uint64_t* rng_state, float* eps_out, float* z_out, float* x_hat, float* mu, float* logvar,
                         float beta, const float* grad_loss, const psvae_grads* grads, float* loss3, void* scratch,
-                        void* stream);
+                        uint32_t flags, void* stream);
 
 /* LatentClassifier training step on latent rows (latent_classifier.py:7-70 as used at lightning.py:73-98):
  * logits = W1 z + b1 (hidden == 0) or W2 relu(W1 z + b1) + b2; loss2 = {mean cross entropy against y, number of rows

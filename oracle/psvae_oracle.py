@@ -498,7 +498,11 @@ def decode_bf16(p, z, normalize_decoder: bool = False):
     return normalize_rows(y)[0] if normalize_decoder else y
 
 
-def train_step_bf16(p, x, eps, beta: float = 1.0, go: float = 1.0, tabs=None, gender=None, age=None):
+def train_step_bf16(p, x, eps, beta: float = 1.0, go: float = 1.0, tabs=None, gender=None, age=None,
+                    normalize_decoder: bool = False, use_cos_loss: bool = False):
+    """bf16 emulation of one training pass; with the loss variants (model.py:60-61 F.normalize on the decoder output,
+    lightning.py:110-111 cosine loss) the decoder's raw fp32 output goes through them in fp32 and the gradient w.r.t. the raw
+    output is rounded to bf16 where the MSE gradient is in the default pass"""
     B, D = x.shape
     W = {k: bf(v) for k, v in p.items() if k.endswith("weight")}
     xb = bf(x)
@@ -524,9 +528,17 @@ def train_step_bf16(p, x, eps, beta: float = 1.0, go: float = 1.0, tabs=None, ge
     d1 = bf(torch.relu(zb @ W["decoder.0.weight"].t() + p["decoder.0.bias"] + rows("decoder", HIDDEN)))
     d2 = bf(torch.relu(d1 @ W["decoder.2.weight"].t() + p["decoder.2.bias"]))
     xh = d2 @ W["decoder.4.weight"].t() + p["decoder.4.bias"]
-    recon, kl, total = elbo(xh, x, mu, lv, beta)
+    if normalize_decoder or use_cos_loss:
+        y = xh.clone().requires_grad_(True)
+        xh = torch.nn.functional.normalize(y, p=2, dim=1) if normalize_decoder else y
+        recon, kl, total = elbo(xh, x, mu, lv, beta, use_cos_loss)
+        (go * recon).backward()
+        gy = bf(y.grad)
+        xh, recon, total = xh.detach(), recon.detach(), total.detach()
+    else:
+        recon, kl, total = elbo(xh, x, mu, lv, beta)
+        gy = bf(go * 2.0 * (xh - x) / (10.0 * B * D))
     g = {}
-    gy = bf(go * 2.0 * (xh - x) / (10.0 * B * D))
 
     def back(gyb, inp, a1, a2, blk, need_dx):
         g[f"{blk}.4.weight"] = gyb.t() @ a2

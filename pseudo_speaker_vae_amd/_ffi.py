@@ -21,7 +21,7 @@ COND_DIM = 6
 NORMALIZE_DECODER = 1
 COS_LOSS = 2
 PHASE_DECODER, PHASE_ENCODER, PHASE_ALL = 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
@@ -132,7 +132,7 @@ def lib() -> C.CDLL:
     L.psvae_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_bf16_scratch_bytes.argtypes = [C.POINTER(Dims)]
     L.psvae_train_step_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), vp, u64, u64, vp, vp,
-                                        vp, vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, vp]
+                                        vp, vp, vp, vp, f32, vp, C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_train_step_bf16.restype = C.c_int
     L.psvae_decode_f32.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp, u32, vp]
     L.psvae_gemm_f32.argtypes = [C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp, vp, C.c_int, C.c_int, vp]
@@ -151,10 +151,10 @@ def lib() -> C.CDLL:
     L.psvae_decode_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_decode_bf16.argtypes = [i64, i64, i64, vp, C.POINTER(vp), vp, vp, u32, vp]
     L.psvae_decode_bf16.restype = C.c_int
-    L.psvae_forward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.psvae_forward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
     L.psvae_forward_bf16.restype = C.c_int
     L.psvae_backward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, f32, vp,
-                                      C.POINTER(Grads), vp, vp, vp]
+                                      C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_backward_bf16.restype = C.c_int
     L.psvae_gather_rows_f32.argtypes = [vp, i64, i64, vp, i64, vp, vp]
     L.psvae_gather_rows_f32.restype = C.c_int

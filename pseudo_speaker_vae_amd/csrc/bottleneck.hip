@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void recon_row_kernel(const float* __restrict_
                                                         float* __restrict__ xh, float* __restrict__ ynorm,
                                                         float* __restrict__ g_y, float* __restrict__ partials,
                                                         const float* __restrict__ go_p, int normalize, int cos_loss,
-                                                        int B, int D) {
+                                                        int B, int D, unsigned short* __restrict__ g_yb) {
     __shared__ float sh4[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + w;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void recon_row_kernel(const float* __restrict_
             s = wave_sum(s);
             n = fmaxf(sqrtf(s), 1e-12f);
             for (int d = lane; d < D; d += 64) xh[o + d] = y[o + d] / n;
-            if (lane == 0) ynorm[row] = n;
+            if (lane == 0 && ynorm) ynorm[row] = n;
         }
         // (without normalisation y IS x_hat: the GEMM epilogue wrote it to xh and y == xh)
         const float* __restrict__ hr = normalize ? xh : y;
@@ -332,8 +332,16 @@ __global__ __launch_bounds__(256) void recon_row_kernel(const float* __restrict_
             const float h = normalize ? y[o + d] / n : hr[o + d], xv = x[o + d];
             return cos_loss ? -(go / (float)B) * (xv / den - cosv * h / a) : cmse * (h - xv);
         };
+        // (bf16 pass: the gradient leaves as bf16, round to nearest even, for the decoder's gradient chain and dW decoder.4)
+        auto emit = [&](int d, float g) {
+            if (g_y) g_y[o + d] = g;
+            if (g_yb) {
+                const __bf16 b = (__bf16)g;
+                g_yb[o + d] = *reinterpret_cast<const unsigned short*>(&b);
+            }
+        };
         if (!normalize) {
-            for (int d = lane; d < D; d += 64) g_y[o + d] = gval(d);
+            for (int d = lane; d < D; d += 64) emit(d, gval(d));
         } else {
             float dot = 0.f;
             for (int d = lane; d < D; d += 64) dot += gval(d) * (y[o + d] / n);
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) void recon_row_kernel(const float* __restrict_
             const bool clamped = n <= 1e-12f;
             for (int d = lane; d < D; d += 64) {
                 const float g = gval(d);
-                g_y[o + d] = clamped ? g / n : (g - (y[o + d] / n) * dot) / n;
+                emit(d, clamped ? g / n : (g - (y[o + d] / n) * dot) / n);
             }
         }
     }
@@ -351,9 +359,10 @@ __global__ __launch_bounds__(256) void recon_row_kernel(const float* __restrict_
 }
 
 hipError_t launch_recon_row(const float* y, const float* x, float* xh, float* ynorm, float* g_y, float* partials,
-                            const float* go, bool normalize, bool cos_loss, int B, int D, hipStream_t s) {
+                            const float* go, bool normalize, bool cos_loss, int B, int D, hipStream_t s,
+                            unsigned short* g_yb) {
     hipLaunchKernelGGL(recon_row_kernel, dim3(recon_row_blocks(B)), dim3(256), 0, s, y, x, xh, ynorm, g_y, partials, go,
-                       (int)normalize, (int)cos_loss, B, D);
+                       (int)normalize, (int)cos_loss, B, D, g_yb);
     return hipGetLastError();
 }
 

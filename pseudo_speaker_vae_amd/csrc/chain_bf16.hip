@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     // decoder: the target rows, piece by piece as the output pass walks them -- requested FIRST: loads return in order, so
     // anything requested after an HBM read waits for it; up front that wait coincides with the input rows'
     f32x4 tv[RECON ? (TR / RPP) * NPC : 1];
-    if (RECON) {
+    if (RECON && !a.raw_out) {
 #pragma unroll
         for (int ps = 0; ps < TR / RPP; ++ps)
 #pragma unroll
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
                 if (row >= a.B) continue;
                 const size_t off = (size_t)row * NOUT + (pc % PPR) * 4;
                 *reinterpret_cast<f32x4*>(a.out + off) = v[i];
-                if (RECON) {
+                if (RECON && !a.raw_out) {
                     const f32x4 xt = tv[ps * NPC + i0 + i];
                     bf16x4 gq;
                     float df[4];
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             }
         }
     }
-    if (RECON) {
+    if (RECON && !a.raw_out) {
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) sq += __shfl_xor(sq, o2);
         if (lane == 0) red[wave] = sq;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
             __syncthreads();
             const float rs = block_sum_256(rr, sh4);
             if (tid == 0) {
-                const float recon = rs / ((float)a.B * (float)a.K0) / 10.0f;
+                const float recon = a.recon_mode ? rs / (float)a.B : rs / ((float)a.B * (float)a.K0) / 10.0f;
                 const float klv = -0.5f * ks / (float)a.B;
                 a.loss3[0] = recon + a.beta * klv;
                 a.loss3[1] = recon;
@@ -783,7 +783,7 @@ static hipError_t launch_chain_t(const ChainBatch& b, int, hipStream_t s) {
 hipError_t launch_chain_fwd_bf16(const ChainBatch& b, hipStream_t s) {
     const ChainArgs& c = b.c[0];
     const int ntiles = 0;
-    const bool recon = c.gy != nullptr;
+    const bool recon = c.gy != nullptr || c.mu != nullptr;  // the decoder of a training pass
 #define PSVAE_ENC(KB0, MB2) if (!recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, false>(b, ntiles, s)
 #define PSVAE_DEC(KB0, MB2) if (recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, true>(b, ntiles, s)
     PSVAE_ENC(8, 1); PSVAE_DEC(2, 4);  // cfg3: encoders 256 -> 64, decoder 64 -> 256

@@ -40,6 +40,7 @@ struct BfScratch {
     u16 *gmu, *glv;                                 // [B,Z]
     u16* oh;                                        // [B,8] one-hot labels (columns 6, 7 zero)
     float *gz, *gmu_f, *glv_f, *kl_partials, *recon_partials;
+    float* y_raw;                                   // [B,D] un-normalised decoder output (PSVAE_NORMALIZE_DECODER only)
     // large batches: weight-gradient partials of the cross-workgroup split (BF_SMAX slices each), summed at the end
     float *slab_w[9], *slab_b[9], *slab_t[3];
     int n_recon_max;
@@ -82,7 +83,9 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
     s.oh = tb(8 * B);
     s.gz = tf(B * Z); s.gmu_f = tf(B * Z); s.glv_f = tf(B * Z);
     s.kl_partials = tf((size_t)reparam_blocks(B * Z));
+    s.y_raw = tf(B * D);
     s.n_recon_max = (int)(((B + 15) / 16) * ((D + 31) / 32));
+    if (s.n_recon_max < recon_row_blocks((int)B)) s.n_recon_max = recon_row_blocks((int)B);
     s.recon_partials = tf((size_t)s.n_recon_max);
     for (int k = 0; k < 9; ++k) {
         s.slab_w[k] = tf((size_t)BF_SMAX * wo[k] * wi[k]);
@@ -116,8 +119,10 @@ size_t psvae_bf16_scratch_bytes(const psvae_dims* dims) {
 static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                      const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
                      float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
-                     const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
+                     const psvae_grads* grads, float* loss3, void* scratch, uint32_t flags, void* stream) {
     const bool fwd = mode & 1, bwd = mode & 2;
+    const bool normalize = flags & PSVAE_NORMALIZE_DECODER, cos_loss = flags & PSVAE_COS_LOSS;
+    if (flags & ~(uint32_t)(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS)) return PSVAE_ERR_ARG;
     if (!dims || !x || !params || !x_hat || !mu || !logvar || !scratch || !eps_out || !z_out) return PSVAE_ERR_NULL;
     if (bwd && (!grads || !loss3)) return PSVAE_ERR_NULL;
     if (dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return PSVAE_ERR_SHAPE;
@@ -139,6 +144,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     int n_recon = sc.n_recon_max;  // backward-only call: every slot (the forward-only call zeroed the unused ones)
     // B >= 2048: each 3-layer MLP as ONE launch over 32/64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
     const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
+    if ((normalize || cos_loss) && !chain) return PSVAE_ERR_SHAPE;  // the loss variants exist on the row-chain path only
     if (fwd) {
     if (chain) {  // (the chains read fp32 x and their own weight packs; x -> bf16 and the one-hot matrix, which only the weight
                   //  gradients read, ride the pack launch below)
@@ -186,8 +192,20 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             cb.c[0].target = x; cb.c[0].go = grad_loss; cb.c[0].scale = 2.0f / (10.0f * (float)B * (float)D);
             cb.c[0].gy = sc.gy; cb.c[0].partials = sc.recon_partials;
             cb.n = 1;
-            RET_IF(launch_chain_fwd_bf16(cb, s));
-            n_recon = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1);
+            if (normalize || cos_loss) {
+                // loss variants (model.py:60-61, lightning.py:110-111): the chain leaves the raw decoder output, the row kernel
+                // of the fp32 fused step (bottleneck.hip) normalises, takes the row's loss term and the gradient w.r.t. the raw
+                // output -- emitted as bf16 here
+                cb.c[0].raw_out = 1;
+                if (normalize) cb.c[0].out = sc.y_raw;
+                RET_IF(launch_chain_fwd_bf16(cb, s));
+                RET_IF(launch_recon_row(normalize ? sc.y_raw : x_hat, x, x_hat, nullptr, nullptr, sc.recon_partials, grad_loss,
+                                        normalize, cos_loss, B, D, s, sc.gy));
+                n_recon = recon_row_blocks(B);
+            } else {
+                RET_IF(launch_chain_fwd_bf16(cb, s));
+                n_recon = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1);
+            }
             if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
         }
     } else {
@@ -297,6 +315,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             c.g_mu = sc.gmu_f; c.g_lv = sc.glv_f; c.gmu_b = sc.gmu; c.glv_b = sc.glv;
             c.kl_partials = sc.kl_partials; c.recon_partials = sc.recon_partials;
             c.n_kl = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1); c.n_recon = n_recon;
+            c.recon_mode = cos_loss ? 1 : 0;
             c.loss3 = loss3; c.rng = eps_in ? nullptr : rng_state; c.nblk = (uint64_t)(((int64_t)B * Z + 3) / 4);
             cb.n = 1;
             RET_IF(launch_chain_bwd_bf16(cb, s));
@@ -401,9 +420,9 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                           const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
                           float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
-                          const psvae_grads* grads, float* loss3, void* scratch, void* stream) {
+                          const psvae_grads* grads, float* loss3, void* scratch, uint32_t flags, void* stream) {
     return bf16_pass(3, dims, x, params, cond, eps_in, seed, offset, rng_state, eps_out, z_out, x_hat, mu, logvar, beta,
-                     grad_loss, grads, loss3, scratch, stream);
+                     grad_loss, grads, loss3, scratch, flags, stream);
 }
 
 // The two halves as separate calls (validation runs only the first).  The forward leaves the bf16 activations, the MSE
@@ -412,18 +431,18 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
 int psvae_forward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                        const float* eps_in, uint64_t seed, uint64_t offset, const uint64_t* rng_state, float* eps_out,
                        float* z_out, float* x_hat, float* mu, float* logvar, const float* grad_loss, void* scratch,
-                       void* stream) {
+                       uint32_t flags, void* stream) {
     return bf16_pass(1, dims, x, params, cond, eps_in, seed, offset, const_cast<uint64_t*>(rng_state), eps_out, z_out, x_hat,
-                     mu, logvar, 1.0f, grad_loss, nullptr, nullptr, scratch, stream);
+                     mu, logvar, 1.0f, grad_loss, nullptr, nullptr, scratch, flags, stream);
 }
 
 int psvae_backward_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                         uint64_t* rng_state, float* eps_out, float* z_out, float* x_hat, float* mu, float* logvar,
                         float beta, const float* grad_loss, const psvae_grads* grads, float* loss3, void* scratch,
-                        void* stream) {
+                        uint32_t flags, void* stream) {
     // eps_in = eps_out marks "epsilon was given": the backward never draws; rng_state (nullable) is advanced
     return bf16_pass(2, dims, x, params, cond, nullptr, 0, 0, rng_state, eps_out, z_out, x_hat, mu, logvar, beta, grad_loss,
-                     grads, loss3, scratch, stream);
+                     grads, loss3, scratch, flags, stream);
 }
 
 // ---- decode-only sampling in bf16 (VAEModel.decode, model.py:65-69; SURVEY 8b psvae_decode_bf16) ----------------

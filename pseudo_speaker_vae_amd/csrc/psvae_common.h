@@ -226,7 +226,8 @@ hipError_t launch_bottleneck_fwd(const BnFwdArgs& a, hipStream_t s);
 hipError_t launch_bottleneck_bwd(const BnBwdArgs& a, hipStream_t s);
 int recon_row_blocks(int B);
 hipError_t launch_recon_row(const float* y, const float* x, float* xh, float* ynorm, float* g_y, float* partials,
-                            const float* go, bool normalize, bool cos_loss, int B, int D, hipStream_t s);
+                            const float* go, bool normalize, bool cos_loss, int B, int D, hipStream_t s,
+                            unsigned short* g_yb = nullptr);  // ynorm, g_y, g_yb nullable; g_yb: the gradient as bf16
 hipError_t launch_adam_dual(const psvae_adam_dev* L, psvae_adam_state* st, double b1, double b2, double eps, double wd,
                             double gscale, hipStream_t s);
 hipError_t launch_reparam_kl(const float* mu, const float* lv, const float* eps_in, const uint64_t* rng,
@@ -313,6 +314,7 @@ struct ChainArgs {
     float* z_out;                    // [B, K0] fp32
     unsigned short* zb;              // [B, K0] bf16
     float* kl_partials;              // [tiles]: sum of 1 + lv - mu^2 - exp(lv)
+    int raw_out;                     // 1: only write the raw third-layer output to `out` (the loss variants' row kernel follows)
 };
 struct ChainBatch {
     ChainArgs c[2];
@@ -345,6 +347,7 @@ struct ChainBwdArgs {
     const float* kl_partials;
     const float* recon_partials;
     int n_kl, n_recon;
+    int recon_mode;                  // 0: recon = sum / (B D) / 10 (MSE); 1: sum / B (cosine loss)
     float* loss3;
     uint64_t* rng;                   // nullable
     uint64_t nblk;

@@ -150,8 +150,9 @@ class TrainEngine:
         self.gender = self.age = self._cond = None
         self.flat_params_t = self.params_t = None
         if dtype == "bf16":
-            if self.flags != 0:
-                raise ValueError("the bf16 path implements the default loss (MSE/10 + beta*KL)")
+            if self.flags != 0 and not (batch >= 64 and input_dim in (128, 256, 512) and latent_dim in (64, 128)):
+                raise ValueError("the bf16 path has the loss variants (normalised decoder output, cosine loss) on its "
+                                 "row-chain shapes only: batch >= 64, input_dim in {128, 256, 512}, latent_dim in {64, 128}")
             self.ws = ops.Bf16Workspace(batch, input_dim, latent_dim, self.device)
             self.outs = (self.ws.x_hat, self.ws.mu, self.ws.logvar)
         else:
@@ -217,7 +218,7 @@ class TrainEngine:
             raise _ffi.PsvaeError("conditional engine: call set_labels(gender, age) for this batch first")
         if self.dtype == "bf16":
             ops.train_step_bf16(self.ws, x, self.params, self.grads, self.loss3, beta=self.beta, eps=eps,
-                                rng_state=self.rng_state, cond=self._cond)
+                                rng_state=self.rng_state, cond=self._cond, flags=self.flags)
             if self.averager is not None and not _local_only:
                 self.averager.reduce_all()
                 self.averager.wait()

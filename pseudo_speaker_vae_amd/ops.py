@@ -252,15 +252,16 @@ class Bf16Workspace:
 
 def train_step_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], loss3,
                     beta: float = 1.0, eps: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-                    rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None, cond=None):
-    """one training pass with bf16 MFMA operands (config 3): psvae_train_step_bf16"""
+                    rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None, cond=None,
+                    flags: int = 0):
+    """one training pass with bf16 MFMA operands (config 3): psvae_train_step_bf16; flags: NORMALIZE_DECODER | COS_LOSS"""
     P = _ffi.make_params(params)
     G = _ffi.make_grads(grads)
     _ffi.check(_ffi.lib().psvae_train_step_bf16(
         C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None,
         _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat),
         _ffi.ptr(ws.mu), _ffi.ptr(ws.logvar), beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3),
-        _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "train_step_bf16")
+        _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()), "train_step_bf16")
 
 
 def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
@@ -287,25 +288,26 @@ def last_decode_launches() -> int:
 
 def forward_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], eps: Optional[torch.Tensor] = None, seed: int = 0,
                  offset: int = 0, rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
-                 cond=None):
+                 cond=None, flags: int = 0):
     """forward half of the bf16 pass (psvae_forward_bf16): fills ws.x_hat / mu / logvar / eps / z and the scratch"""
     P = _ffi.make_params(params)
     _ffi.check(_ffi.lib().psvae_forward_bf16(
         C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None, _ffi.ptr(eps),
         seed, offset, _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat), _ffi.ptr(ws.mu),
-        _ffi.ptr(ws.logvar), _ffi.ptr(grad_loss), _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "forward_bf16")
+        _ffi.ptr(ws.logvar), _ffi.ptr(grad_loss), _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()), "forward_bf16")
 
 
 def backward_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], loss3,
                   beta: float = 1.0, rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None,
-                  cond=None):
-    """backward half (psvae_backward_bf16) on the workspace a forward_bf16 call just filled"""
+                  cond=None, flags: int = 0):
+    """backward half (psvae_backward_bf16) on the workspace a forward_bf16 call just filled (same flags)"""
     P = _ffi.make_params(params)
     G = _ffi.make_grads(grads)
     _ffi.check(_ffi.lib().psvae_backward_bf16(
         C.byref(ws.dims), _ffi.ptr(_f32(x, "x")), C.byref(P), C.byref(cond) if cond is not None else None,
         _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat), _ffi.ptr(ws.mu), _ffi.ptr(ws.logvar),
-        beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), _ffi.stream_ptr()), "backward_bf16")
+        beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3), _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()),
+        "backward_bf16")
 
 
 def decode_bf16(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
