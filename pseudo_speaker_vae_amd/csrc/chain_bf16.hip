@@ -22,6 +22,10 @@
 #include "psvae_common.h"
 #include "psvae_device.h"
 
+#ifndef PSVAE_CHAIN_NA
+#define PSVAE_CHAIN_NA 3  // ring depth of the weight fragments at 32-row tiles: 3 / 4 / 5 measured 121.6 / 122.0 / 121.7 us per cfg3 step
+#endif
+
 namespace psvae {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     CSTAMP(0);
     constexpr int HK = H / 32;                       // 16 k steps of a hidden input
     constexpr int S = KB0 + HK + HK;                 // k steps of the weight stream
-    constexpr int NA = 3;
+    constexpr int NA = RG <= 2 ? PSVAE_CHAIN_NA : 3;  // weight-fragment ring: this k step and NA - 1 ahead (registers allow more at 32 rows)
     const ChainArgs& a = batch.c[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* act = reinterpret_cast<char*>(lds);        // image [16][RG][64][16 B]
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 #pragma unroll
         for (int g = 0; g < RG; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
     };
-    wfetch(0);
-    wfetch(1);
+#pragma unroll
+    for (int s0 = 0; s0 < NA - 1; ++s0) wfetch(s0);
 
     // ---- prologue: every global read goes out before the first one is consumed (one memory round trip, not five) -----
     constexpr int NOUT = 64 * MB2;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb, ++s) {
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < S) wfetch(s + 2);
+            if (s + NA - 1 < S) wfetch(s + NA - 1);
             if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
     constexpr int STG = TR * SROW;
     constexpr int HK = H / 32;
     constexpr int S = KB0 + HK + (MB2 > 0 ? HK : 0);
-    constexpr int NA = 3;
+    constexpr int NA = RG <= 2 ? PSVAE_CHAIN_NA : 3;  // weight-fragment ring: this k step and NA - 1 ahead (registers allow more at 32 rows)
     const ChainBwdArgs& a = batch.c[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* act = reinterpret_cast<char*>(lds);
@@ -494,8 +498,8 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
 #pragma unroll
         for (int g = 0; g < RG; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
     };
-    wfetch(0);
-    wfetch(1);
+#pragma unroll
+    for (int s0 = 0; s0 < NA - 1; ++s0) wfetch(s0);
     // ---- prologue: input rows and both layers' masks go out together ---------------------------------------------------
     constexpr int NIN = (RG * KB0 + 3) / 4;
     f32x4 vin[IN_BF16 ? 1 : NIN][2];
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb, ++s) {
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < S) wfetch(s + 2);
+            if (s + NA - 1 < S) wfetch(s + NA - 1);
             if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
