@@ -243,6 +243,9 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
                        float noise_weight, int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
                        float* history, void* stream);
 
+/* kernel launches the calling thread's most recent bf16 pass (train step, forward or backward call) issued */
+int psvae_last_step_launches_bf16(void);
+
 /* The two halves of psvae_train_step_bf16 as separate calls (a validation step runs only the first).  The forward leaves
  * the bf16 activations, the MSE gradient (already times *grad_loss) and the loss partial sums in `scratch`; the backward
  * must be given the same scratch, x, params, cond, eps_out, mu and logvar, untouched.  rng_state (nullable) supplies

@@ -32,7 +32,7 @@ SYMBOLS = (
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
-    "psvae_last_decode_launches",
+    "psvae_last_decode_launches", "psvae_last_step_launches_bf16",
 )
 
 
@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
     L.psvae_last_step_launches.argtypes = []
     L.psvae_last_decode_launches.restype = C.c_int
     L.psvae_last_decode_launches.argtypes = []
+    L.psvae_last_step_launches_bf16.restype = C.c_int
+    L.psvae_last_step_launches_bf16.argtypes = []
     L.psvae_transpose_params_f32.argtypes = [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), vp]
     L.psvae_transpose_params_f32.restype = C.c_int
     L.psvae_adam_step_dev_f32.argtypes = [C.POINTER(AdamDev), vp, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -96,6 +96,8 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
     return s;
 }
 
+thread_local int t_bf_launches = 0;  // launches of this thread's current / last bf16 pass
+
 inline GemmDescBf bdesc(int M, int N, int K, const u16* A, int lda, const u16* B, int ldb) {
     GemmDescBf d{};
     d.A = A; d.B = B; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb;
@@ -121,6 +123,8 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
                      float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,
                      const psvae_grads* grads, float* loss3, void* scratch, uint32_t flags, void* stream) {
     const bool fwd = mode & 1, bwd = mode & 2;
+    t_bf_launches = 0;
+#define LAUNCH(e) do { RET_IF(e); ++t_bf_launches; } while (0)
     const bool normalize = flags & PSVAE_NORMALIZE_DECODER, cos_loss = flags & PSVAE_COS_LOSS;
     if (flags & ~(uint32_t)(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS)) return PSVAE_ERR_ARG;
     if (!dims || !x || !params || !x_hat || !mu || !logvar || !scratch || !eps_out || !z_out) return PSVAE_ERR_NULL;
@@ -156,7 +160,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         }
         src[9] = x; dst[9] = sc.xb; dstT[9] = nullptr; R[9] = B; C[9] = D; ld[9] = D; ldt[9] = 0;
         // (+ the one-hot label matrix for the conditional-table gradients, as rider blocks)
-        RET_IF(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
+        LAUNCH(launch_cast_transpose(src, dst, dstT, R, C, ld, ldt, 10, s, has_cond ? cond->gender : nullptr,
                                      has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
     }
     if (chain) {
@@ -165,7 +169,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         for (int k = 0; k < 9; ++k) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.Wc[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 0; }
         for (int k = 0; k < 9; ++k)
             if (k != 0 && k != 3) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.WcT[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 1; }
-        RET_IF(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, x, sc.xb, (long)B * D, has_cond ? cond->gender : nullptr,
+        LAUNCH(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, x, sc.xb, (long)B * D, has_cond ? cond->gender : nullptr,
                                  has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B, s));
         auto mlp = [&](const float* in, int K0, int NOUT, int w0, u16* s0, u16* s1, float* out, const float* ctab) {
             ChainArgs c{};
@@ -180,7 +184,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             cb.c[0] = mlp(x, D, Z, 0, sc.h1m, sc.h2m, mu, has_cond ? cond->tab[0] : nullptr);
             cb.c[1] = mlp(x, D, Z, 3, sc.h1s, sc.h2s, logvar, has_cond ? cond->tab[1] : nullptr);
             cb.n = 2;
-            RET_IF(launch_chain_fwd_bf16(cb, s));
+            LAUNCH(launch_chain_fwd_bf16(cb, s));
         }
         if (!bwd) RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
         {   // decoder chain; its input stage is the reparameterisation (eps, z, z in bf16, KL partial per tile)
@@ -198,12 +202,12 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
                 // output -- emitted as bf16 here
                 cb.c[0].raw_out = 1;
                 if (normalize) cb.c[0].out = sc.y_raw;
-                RET_IF(launch_chain_fwd_bf16(cb, s));
-                RET_IF(launch_recon_row(normalize ? sc.y_raw : x_hat, x, x_hat, nullptr, nullptr, sc.recon_partials, grad_loss,
+                LAUNCH(launch_chain_fwd_bf16(cb, s));
+                LAUNCH(launch_recon_row(normalize ? sc.y_raw : x_hat, x, x_hat, nullptr, nullptr, sc.recon_partials, grad_loss,
                                         normalize, cos_loss, B, D, s, sc.gy));
                 n_recon = recon_row_blocks(B);
             } else {
-                RET_IF(launch_chain_fwd_bf16(cb, s));
+                LAUNCH(launch_chain_fwd_bf16(cb, s));
                 n_recon = (B + chain_rows_per_tile(B, 1) - 1) / chain_rows_per_tile(B, 1);
             }
             if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
@@ -219,13 +223,13 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         GemmBatchBf b{};
         addb(b, hidden(sc.xb, D, 0, sc.h1m, has_cond ? cond->tab[0] : nullptr));
         addb(b, hidden(sc.xb, D, 3, sc.h1s, has_cond ? cond->tab[1] : nullptr));
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
         addb(b, hidden(sc.h1m, H, 1, sc.h2m, nullptr));
         addb(b, hidden(sc.h1s, H, 4, sc.h2s, nullptr));
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {  // heads: fp32 outputs
         GemmBatchBf b{};
@@ -234,20 +238,20 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         GemmDescBf ds = bdesc(B, Z, H, sc.h2s, H, sc.Wb[5], H);
         ds.bias = P[11]; ds.Cf = logvar; ds.ldcf = Z;
         addb(b, dm); addb(b, ds);
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     // reparameterisation + KL partials; the kernel also writes z as bf16 (no cast launch)
-    RET_IF(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
+    LAUNCH(launch_reparam_kl(mu, logvar, eps_in, rng_state, seed, offset, eps_out, z_out, sc.kl_partials,
                              (int64_t)B * Z, s, sc.zb));
     {
         GemmBatchBf b{};
         addb(b, hidden(sc.zb, Z, 6, sc.d1, has_cond ? cond->tab[2] : nullptr));
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
         addb(b, hidden(sc.d1, H, 7, sc.d2, nullptr));
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     if (!bwd)  // forward-only call: the backward call sums ALL partial slots, so the unused ones must be zero
         RET_IF(hipMemsetAsync(sc.recon_partials, 0, (size_t)sc.n_recon_max * sizeof(float), s));
@@ -258,7 +262,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         d.scale = 2.0f / (10.0f * (float)B * (float)D);
         d.Cb = sc.gy; d.ldcb = D; d.partials = sc.recon_partials;
         addb(b, d);
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
         n_recon = b.d[0].tiles_m * b.d[0].tiles_n;
         if (n_recon > sc.n_recon_max) return PSVAE_ERR_STATE;
     }
@@ -318,7 +322,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             c.recon_mode = cos_loss ? 1 : 0;
             c.loss3 = loss3; c.rng = eps_in ? nullptr : rng_state; c.nblk = (uint64_t)(((int64_t)B * Z + 3) / 4);
             cb.n = 1;
-            RET_IF(launch_chain_bwd_bf16(cb, s));
+            LAUNCH(launch_chain_bwd_bf16(cb, s));
         }
         {
             ChainBwdBatch cb{};
@@ -330,7 +334,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
                 c.save[0] = e ? sc.dh2s : sc.dh2m; c.save[1] = e ? sc.dh1s : sc.dh1m; c.out = nullptr;
             }
             cb.n = 2;
-            RET_IF(launch_chain_bwd_bf16(cb, s));
+            LAUNCH(launch_chain_bwd_bf16(cb, s));
         }
         {
             GemmBatchBf b{};
@@ -349,9 +353,9 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
                 addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
             }
             b.force_staged = 1;
-            RET_IF(launch_gemm_batch_bf16(b, s));
+            LAUNCH(launch_gemm_batch_bf16(b, s));
         }
-        if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
+        if (nred) LAUNCH(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
         return 0;
     }
     {
@@ -359,14 +363,14 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         addb(b, wgrad(sc.gy, D, D, sc.d2, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
         addb(b, dgrad(sc.gy, D, 8, H, sc.dd2, sc.d2));
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
         addb(b, wgrad(sc.dd2, H, H, sc.d1, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
         addb(b, dgrad(sc.dd2, H, 7, H, sc.dd1, sc.d1));
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
@@ -376,11 +380,11 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         gz.Cf = sc.gz; gz.ldcf = Z;
         addb(b, gz);
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {   // g_mu / g_logvar (+ loss finalize, rng advance); the kernel also writes their bf16 copies
         u16* rm[2] = {sc.gmu, sc.glv};
-        RET_IF(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
+        LAUNCH(launch_reparam_bwd_final(sc.gz, mu, logvar, eps_out, beta, grad_loss, sc.gmu_f, sc.glv_f, B, Z, D,
                                         sc.kl_partials, reparam_blocks((int64_t)B * Z), sc.recon_partials, n_recon, loss3,
                                         eps_in ? nullptr : rng_state, s, rm));
     }
@@ -391,7 +395,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         addb(b, dgrad(sc.gmu, Z, 2, H, sc.dh2m, sc.h2m));
         addb(b, dgrad(sc.glv, Z, 5, H, sc.dh2s, sc.h2s));
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
@@ -400,7 +404,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         addb(b, dgrad(sc.dh2m, H, 1, H, sc.dh1m, sc.h1m));
         addb(b, dgrad(sc.dh2s, H, 4, H, sc.dh1s, sc.h1s));
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
     {
         GemmBatchBf b{};
@@ -411,11 +415,15 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
             addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
         }
         b.force_staged = 1;
-        RET_IF(launch_gemm_batch_bf16(b, s));
+        LAUNCH(launch_gemm_batch_bf16(b, s));
     }
-    if (nred) RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
+    if (nred) LAUNCH(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
     return 0;
 }
+
+#undef LAUNCH
+
+int psvae_last_step_launches_bf16(void) { return t_bf_launches; }
 
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                           const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,

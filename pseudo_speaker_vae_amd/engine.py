@@ -195,10 +195,8 @@ class TrainEngine:
 
     def launches_per_step(self) -> Optional[int]:
         """kernel launches of one forward+ELBO+backward pass as this engine issues it (measured: the library counts
-        the launches of the calling thread's last psvae_train_step_f32).  None for the bf16 path (not instrumented)."""
-        if self.dtype != "f32":
-            return None
-        n = ops.last_step_launches()
+        the launches of the calling thread's last psvae_train_step_f32 / bf16 pass)."""
+        n = ops.last_step_launches() if self.dtype == "f32" else ops.last_step_launches_bf16()
         return n if n > 0 else None
 
     def forward_backward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, _local_only: bool = False):

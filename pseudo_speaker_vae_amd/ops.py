@@ -281,6 +281,11 @@ def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: i
     return xh
 
 
+def last_step_launches_bf16() -> int:
+    """launches of this thread's most recent bf16 pass (7 = the row-chain path at its default loss)"""
+    return int(_ffi.lib().psvae_last_step_launches_bf16())
+
+
 def last_decode_launches() -> int:
     """launches of this thread's most recent decode call (4 + normalisation = the fused three-layer kernel ran)"""
     return int(_ffi.lib().psvae_last_decode_launches())

@@ -120,6 +120,11 @@ def _check_train_step(D, Z, B, cond, flags=0):
     losses, ref, outs, tg = O.train_step_bf16(p, x, eps, 0.7, go, tabs, gender, age,
                                               normalize_decoder=bool(flags & _ffi.NORMALIZE_DECODER),
                                               use_cos_loss=bool(flags & _ffi.COS_LOSS))
+    import os
+    chains = (B >= int(os.environ.get("PSVAE_BF16_CHAIN_MIN", 64)) and not os.environ.get("PSVAE_BF16_NO_CHAIN")
+              and D in (128, 256, 512) and Z in (64, 128))
+    if chains:  # pack, encoders, decoder (+ the variants' row kernel), two gradient chains, weight gradients, slab sums
+        assert ops.last_step_launches_bf16() in ((7, 6) if not flags else (8, 7)), ops.last_step_launches_bf16()
     assert_close(ws.x_hat.cpu(), outs["x_hat"], BF16_TOL, "x_hat")
     assert_close(ws.mu.cpu(), outs["mu"], BF16_TOL, "mu")
     assert_close(ws.logvar.cpu(), outs["logvar"], BF16_TOL, "logvar")
