@@ -79,6 +79,37 @@ def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group,
     assert float(eng.loss3[0]) == float(ref.loss3[0]) and torch.isfinite(eng.flat_grads).all()
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph_then_allreduce"])
+def test_one_rank_rccl_bf16_engine_matches_the_engine_without_a_group(nccl_group, mode):
+    """the bf16 pass (row chains, 7 launches) under a process group: same gradients, loss scalars and Philox state as
+    without one, eager and captured"""
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    x = torch.randn(B, D, device=DEV)
+    kw = dict(device=DEV, seed=9, beta=0.6, dtype="bf16", conditional=True)
+    ref = TrainEngine(D, Z, B, **kw)
+    eng = TrainEngine(D, Z, B, process_group=nccl_group, **kw)
+    g = torch.Generator().manual_seed(3)
+    gender, age = torch.randint(-1, 3, (B,), generator=g), torch.randint(-1, 3, (B,), generator=g)
+    ref.set_labels(gender, age)
+    eng.set_labels(gender, age)
+    warm = 0
+    if mode == "eager":
+        step = lambda: eng.forward_backward(x)
+    else:
+        eng.capture(x)
+        warm, step = 2, eng.replay
+    for _ in range(warm):
+        ref.forward_backward(x)
+    for it in range(3):
+        ref.forward_backward(x)
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(ref.flat_grads, eng.flat_grads), f"{mode} step {it}: gradients / loss scalars differ"
+        assert torch.equal(ref.rng_state, eng.rng_state), f"{mode} step {it}: Philox state differs"
+        assert torch.equal(ref.ws.eps, eng.ws.eps), f"{mode} step {it}: epsilon differs"
+    assert eng.launches_per_step() == 7 and torch.isfinite(eng.flat_grads).all()
+
+
 def test_one_rank_rccl_optimizer_after_the_exchange(nccl_group):
     """the whole data-parallel iteration: captured step, all-reduce, fused Adam -- same parameters as without a group"""
     from pseudo_speaker_vae_amd.engine import TrainEngine
