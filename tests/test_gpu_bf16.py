@@ -234,3 +234,28 @@ def test_bf16_engine_runs_the_loss_variants():
         assert l2 < 0.1, f"grad {k}: relative L2 distance {l2:.3e} from the fp32 engine"
     with pytest.raises(ValueError):
         TrainEngine(64, 32, 128, dtype="bf16", device=DEV, use_cos_loss=True)
+
+
+@pytest.mark.parametrize("B", [4096, 300])
+def test_bf16_pass_draws_the_same_philox_epsilon_as_the_fp32_path(B):
+    """the decoder chain's input stage draws epsilon itself: same Philox block per element as reparam_kl_kernel / the fp32
+    step (block = flat element index / 4 from the device-resident {seed, offset}), and the backward advances the state by
+    the blocks the batch consumed"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z = 256, 64
+    p = O.init_params(D, Z, 5)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(B)).to(DEV)
+    ws = ops.Bf16Workspace(B, D, Z, DEV)
+    state = torch.tensor([1234, 777], dtype=torch.int64, device=DEV)
+    grads = [torch.empty_like(t) for t in params]
+    loss3 = torch.empty(3, device=DEV)
+    ops.train_step_bf16(ws, x, params, grads, loss3, rng_state=state)
+    torch.cuda.synchronize()
+    assert ops.last_step_launches_bf16() in (6, 7)  # (no slab sums where the batch is one slice)
+    ref = ops.philox_normal(B * Z, 1234, 777, DEV).view(B, Z)
+    assert torch.equal(ws.eps, ref)
+    assert int(state[1]) == 777 + B * Z // 4 and int(state[0]) == 1234
+    z = ws.mu + torch.exp(0.5 * ws.logvar) * ws.eps
+    assert_close(ws.z.cpu(), z.cpu(), 1e-6, "z = mu + exp(logvar / 2) eps")
+    assert torch.isfinite(loss3).all()
