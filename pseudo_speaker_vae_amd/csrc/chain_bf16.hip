@@ -16,6 +16,10 @@
 //            gy = bf16(scale * go * (x_hat - x)) and the tile's sum of squared errors (lightning.py:113, BEPI_RECON's job)
 // Same rounding points as the per-layer path; sums in a different order (the bias is the accumulator's initial value),
 // so a hidden activation near a rounding boundary may land on the other bf16 neighbour.
+// Further down: chain_pack_kernel (the weights in fragment order, plain and transposed, + the x cast and the one-hot matrix)
+// and chain_bwd_bf16_kernel (the input-gradient path of an MLP, same organisation).  A training pass is then 7 launches:
+// pack, encoders, decoder, decoder gradient chain, encoder gradient chains, all weight gradients, slab sums
+// (psvae_api_bf16.hip).
 #include <mutex>
 #include <type_traits>
 
@@ -779,17 +783,16 @@ int chain_rows_per_tile(int B, int nchains) {
 }
 
 template <int KB0, int MB2, bool RECON>
-static hipError_t launch_chain_t(const ChainBatch& b, int, hipStream_t s) {
+static hipError_t launch_chain_t(const ChainBatch& b, hipStream_t s) {
     return chain_rows_per_tile(b.c[0].B, b.n) == 32 ? launch_chain_rg<KB0, MB2, RECON, 2>(b, s) : launch_chain_rg<KB0, MB2, RECON, 4>(b, s);
 }
 
 // every chain of a batch has the same B, K0 and NOUT (the two encoders; or the decoder alone)
 hipError_t launch_chain_fwd_bf16(const ChainBatch& b, hipStream_t s) {
     const ChainArgs& c = b.c[0];
-    const int ntiles = 0;
     const bool recon = c.gy != nullptr || c.mu != nullptr;  // the decoder of a training pass
-#define PSVAE_ENC(KB0, MB2) if (!recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, false>(b, ntiles, s)
-#define PSVAE_DEC(KB0, MB2) if (recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, true>(b, ntiles, s)
+#define PSVAE_ENC(KB0, MB2) if (!recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, false>(b, s)
+#define PSVAE_DEC(KB0, MB2) if (recon && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) return launch_chain_t<KB0, MB2, true>(b, s)
     PSVAE_ENC(8, 1); PSVAE_DEC(2, 4);  // cfg3: encoders 256 -> 64, decoder 64 -> 256
     PSVAE_ENC(4, 1); PSVAE_ENC(16, 1); PSVAE_ENC(4, 2); PSVAE_ENC(8, 2); PSVAE_ENC(16, 2);
     PSVAE_DEC(2, 2); PSVAE_DEC(2, 8); PSVAE_DEC(4, 2); PSVAE_DEC(4, 4); PSVAE_DEC(4, 8);
