@@ -259,3 +259,37 @@ def test_bf16_pass_draws_the_same_philox_epsilon_as_the_fp32_path(B):
     z = ws.mu + torch.exp(0.5 * ws.logvar) * ws.eps
     assert_close(ws.z.cpu(), z.cpu(), 1e-6, "z = mu + exp(logvar / 2) eps")
     assert torch.isfinite(loss3).all()
+
+
+def test_bf16_row_chains_are_deterministic_and_row_local():
+    """size-independent properties at cfg3's size: a second run is bit-identical (fixed-order slab sums, no atomics), and every
+    row's forward depends on that row alone -- the first 2,048 rows run as their own batch reproduce the big run's rows bit
+    for bit (tile boundaries are invisible), the loss partials add up, and the weight gradients are the row-shards' mean"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z, B = 256, 64, 4096
+    p = O.init_params(D, Z, 8)
+    params = [p[k].to(DEV) for k in O.PARAM_KEYS]
+    g = torch.Generator().manual_seed(4)
+    x, eps = torch.randn(B, D, generator=g).to(DEV), torch.randn(B, Z, generator=g).to(DEV)
+
+    def run(xs, es):
+        ws = ops.Bf16Workspace(xs.shape[0], D, Z, DEV)
+        grads = [torch.full_like(t, float("nan")) for t in params]
+        loss3 = torch.full((3,), float("nan"), device=DEV)
+        ops.train_step_bf16(ws, xs, params, grads, loss3, beta=0.5, eps=es)
+        torch.cuda.synchronize()
+        return ws, grads, loss3
+
+    w1, g1, l1 = run(x, eps)
+    w2, g2, l2 = run(x, eps)
+    assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(g1, g2)) and torch.equal(w1.x_hat, w2.x_hat)
+    halves = [run(x[h * 2048:(h + 1) * 2048].contiguous(), eps[h * 2048:(h + 1) * 2048].contiguous()) for h in range(2)]
+    for h, (wh, gh, lh) in enumerate(halves):
+        sl = slice(h * 2048, (h + 1) * 2048)
+        assert torch.equal(wh.mu, w1.mu[sl]) and torch.equal(wh.logvar, w1.logvar[sl]) and torch.equal(wh.x_hat, w1.x_hat[sl])
+    lm = (halves[0][2] + halves[1][2]) / 2
+    assert_close(lm.cpu(), l1.cpu(), 2e-6, "loss = mean of the halves' losses")
+    for k, a, b0, b1 in zip(O.PARAM_KEYS, g1, halves[0][1], halves[1][1]):
+        # (each half normalises by its own 2,048 rows and rounds its MSE / KL gradients to bf16 at that scale: the mean of
+        #  the shards' gradients equals the full-batch gradient up to those roundings)
+        assert_close_bf16(((b0 + b1) / 2).cpu(), a.cpu(), "shard mean " + k)
