@@ -465,6 +465,10 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 // layout (16 rows x 32 B per instruction -- 32 KB per activation and tile, requested in the prologue with everything else).
 template <int KB0, int MB2, bool IN_BF16, int RG>
 __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBatch batch) {
+#ifdef PSVAE_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    CSTAMP(0);
     constexpr int TR = 16 * RG;
     constexpr int IMG = 16 * RG * 1024;
     constexpr int STG = TR * SROW;
@@ -637,12 +641,18 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
             }
         }
     };
+    CSTAMP(1);
     layer(std::integral_constant<int, KB0>{}, std::integral_constant<int, 8>{});
+    CSTAMP(2);
     publish(a.save[0], 0);
+    CSTAMP(3);
     layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{});
+    CSTAMP(4);
     publish(a.save[1], 1);
+    CSTAMP(5);
     if constexpr (MB2 > 0) {
         layer(std::integral_constant<int, HK>{}, std::integral_constant<int, MB2>{});
+        CSTAMP(6);
         constexpr int NOUT = 64 * MB2;
         constexpr int OROW = NOUT * 4 + 16;
         static_assert(OROW * TR <= STG, "staging buffer too small for the output rows");
@@ -705,6 +715,12 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
             }
         }
     }
+    CSTAMP(7);
+#ifdef PSVAE_STAMP
+    if (MB2 == 0) st_[6] = st_[5];  // (no third layer)
+    if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 0)
+        for (int i = 0; i < 8; ++i) g_cstamp[MB2 > 0 ? 0 : 1][i] = st_[i];
+#endif
 }
 
 template <int KB0, int MB2, bool IN_BF16, int RG>
@@ -720,6 +736,17 @@ static hipError_t launch_chain_bwd_rg(const ChainBwdBatch& b, hipStream_t s) {
     if (attr_err != hipSuccess) return attr_err;
     const int ntiles = (b.c[0].B + TR - 1) / TR;
     hipLaunchKernelGGL((chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>), dim3(ntiles, b.n), dim3(256), lds, s, b);
+#ifdef PSVAE_STAMP
+    {
+        unsigned long long h[2][8];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cstamp), sizeof(h)) == hipSuccess) {
+            const int w = MB2 > 0 ? 0 : 1;
+            printf("chain gradient %s stamps (cycles): prologue | L0 | publish | L1 | publish | L2 | output:", w ? "encoder" : "decoder");
+            for (int i = 1; i < 8; ++i) printf(" %llu", h[w][i] > h[w][i - 1] ? h[w][i] - h[w][i - 1] : 0ull);
+            printf("\n");
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
