@@ -92,9 +92,13 @@ def langevin_fused(clf_params, z: torch.Tensor, target: int, step_size: float, n
 
 def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[int, dict], step_size: float = 0.01,
                           num_steps: int = 100, noise_weight: float = 1.0, return_history: bool = False,
-                          device: str = "cuda", z0: Optional[torch.Tensor] = None, noises=None):
-    """inference.py:29-110.  `z0` / `noises` (optional) inject the initial point and the per-step
-    noise (parity tests); by default both come from torch's generator on `device`."""
+                          device: str = "cpu", z0: Optional[torch.Tensor] = None, noises=None):
+    """inference.py:29-110, same signature and defaults (`device="cpu"`, inference.py:37).  There is no CPU path:
+    a non-GPU `device` raises, naming what to pass.  `z0` / `noises` (optional) inject the initial point and the
+    per-step noise (parity tests); by default both come from torch's generator on `device`."""
+    if torch.device(device).type != "cuda":
+        raise RuntimeError(f"conditional_synthesis: GPU only (MI355X HIP path, no CPU fallback): got device={device!r}; "
+                           "pass device='cuda' (inference.py --device cuda) with the model moved there")
     dim = _latent_dim(vae_model)
     fus = _fusable_classifier(getattr(vae_model, "classifier", None), classifier_target)
     if fus is not None and torch.device(device).type == "cuda":

@@ -136,3 +136,17 @@ def test_flat_layout_buckets():
     # views do not overlap
     ends = [o + s.numel() for o, s in zip(lay.offsets, shapes)]
     assert all(e <= o2 for e, o2 in zip(ends[:-1], lay.offsets[1:]))
+
+
+def test_conditional_synthesis_signature_is_the_reference_one():
+    """inference.py:29-38: same parameter names, order and defaults (device="cpu" included); the extra keyword-only
+    hooks come after them.  The default device has no CPU path here and says so."""
+    import inspect
+    from ps_vae.inference import conditional_synthesis, unconditional_synthesis
+    sig = inspect.signature(conditional_synthesis)
+    ref = [("vae_model", inspect._empty), ("num_samples", inspect._empty), ("classifier_target", inspect._empty),
+           ("step_size", 0.01), ("num_steps", 100), ("noise_weight", 1.0), ("return_history", False), ("device", "cpu")]
+    assert [(n, p.default) for n, p in list(sig.parameters.items())[:len(ref)]] == ref
+    assert list(inspect.signature(unconditional_synthesis).parameters)[:3] == ["vae_model", "num_samples", "device"]
+    with pytest.raises(RuntimeError, match="GPU only"):
+        conditional_synthesis(object(), 4, 1)
