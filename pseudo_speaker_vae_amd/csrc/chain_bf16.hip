@@ -20,7 +20,6 @@
 // and chain_bwd_bf16_kernel (the input-gradient path of an MLP, same organisation).  A training pass is then 7 launches:
 // pack, encoders, decoder, decoder gradient chain, encoder gradient chains, all weight gradients, slab sums
 // (psvae_api_bf16.hip).
-#include <mutex>
 #include <type_traits>
 
 #include "psvae_common.h"
@@ -727,13 +726,9 @@ template <int KB0, int MB2, bool IN_BF16, int RG>
 static hipError_t launch_chain_bwd_rg(const ChainBwdBatch& b, hipStream_t s) {
     constexpr int TR = 16 * RG;
     constexpr size_t lds = (size_t)16 * RG * 1024 + (size_t)TR * SROW;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>), 160 * 1024))
+        return attr_err;
     const int ntiles = (b.c[0].B + TR - 1) / TR;
     hipLaunchKernelGGL((chain_bwd_bf16_kernel<KB0, MB2, IN_BF16, RG>), dim3(ntiles, b.n), dim3(256), lds, s, b);
 #ifdef PSVAE_STAMP
@@ -782,13 +777,9 @@ static hipError_t launch_chain_rg(const ChainBatch& b, hipStream_t s) {
     constexpr size_t lds = (size_t)16 * RG * 1024 + (size_t)TR * SROW + (size_t)(2 * H + 64 * MB2 + 7 * H + 4) * sizeof(float);
     const int ntiles = (b.c[0].B + TR - 1) / TR;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_fwd_bf16_kernel<KB0, MB2, RECON, RG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&chain_fwd_bf16_kernel<KB0, MB2, RECON, RG>), 160 * 1024))
+        return attr_err;
     hipLaunchKernelGGL((chain_fwd_bf16_kernel<KB0, MB2, RECON, RG>), dim3(ntiles, b.n), dim3(256), lds, s, b);
 #ifdef PSVAE_STAMP
     {

@@ -186,13 +186,11 @@ hipError_t launch_classifier_ce(int64_t B, int Z, int hidden, int C, const float
     const int grid = classifier_blocks(B);
 #define PSVAE_CL(ZD)                                                                                                  \
     case ZD: {                                                                                                        \
-        static bool done = false;                                                                                     \
-        if (!done && lds > 48 * 1024) {                                                                               \
+        static std::atomic<unsigned long long> lds_ok{0}; /* per device: psvae_common.h lds_opt_in */                \
+        if (lds > 48 * 1024) {                                                                                        \
             /* (the kernel also has 32 B of static LDS: the dynamic limit must leave room for it) */                  \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&classifier_ce_kernel<ZD>),             \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);              \
+            hipError_t ea = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&classifier_ce_kernel<ZD>), 159 * 1024); \
             if (ea != hipSuccess) return ea;                                                                          \
-            done = true;                                                                                              \
         }                                                                                                             \
         hipLaunchKernelGGL(classifier_ce_kernel<ZD>, dim3(grid), dim3(256), lds, s, B, hidden, C, z, y, W1, b1, W2, b2, \
                            scale, h_out, dh_out, dlogits, g_z, partials, relu_input);                                           \

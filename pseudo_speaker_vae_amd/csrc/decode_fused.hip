@@ -12,7 +12,6 @@
 // workgroup stream them global -> registers -> LDS as plain 16-byte copies (32 KB chunks, three LDS buffers, one
 // barrier per chunk of 128 MFMAs per wavefront) and read their fragments as contiguous ds_read_b128.
 // Per 16 rows: 6,656 MFMAs (Z = 64, D = 256) against 96 KB of LDS fragment reads per wavefront -- MFMA-bound.
-#include <mutex>
 #include <type_traits>
 
 #include "psvae_common.h"
@@ -221,13 +220,9 @@ bool decode_fused_ok(int64_t N, int Z, int D) {
 template <int ZB, int DB>
 static hipError_t launch_decode_fused_t(const DecodeFusedArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(3 * 4 * 4 * 16 * (H / 16) + 2 * H + 16 * DB) * sizeof(float);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_fused_kernel<ZB, DB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_fused_kernel<ZB, DB>), 160 * 1024))
+        return attr_err;
     const long ntiles = (a.N + 63) / 64;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // persistent: one workgroup per CU walks the row tiles
     hipLaunchKernelGGL((decode_fused_kernel<ZB, DB>), dim3(grid), dim3(256), lds, s, a);
@@ -516,13 +511,9 @@ template <int ZK, int DBW>
 static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
     constexpr int RPP = DBW == 8 ? 64 : 128, RS = 256 * DBW + 16;
     constexpr size_t lds = (size_t)(RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024) + (size_t)(2 * H + 64 * DBW) * sizeof(float);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW>), 160 * 1024))
+        return attr_err;
     const long ntiles = (a.N + 127) / 128;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
     hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW>), dim3(grid), dim3(256), lds, s, a);

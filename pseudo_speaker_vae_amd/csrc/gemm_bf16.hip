@@ -15,7 +15,6 @@
 // waves, one LDS meeting point for the k slices, fused epilogue writing fp32 and/or both bf16 layouts.
 #include <hip/hip_bf16.h>
 
-#include <mutex>
 #include <type_traits>
 
 #include "psvae_common.h"
@@ -606,13 +605,9 @@ static hipError_t launch_bf_ct(GemmBatchBf& b, hipStream_t stream) {
         const char* e = getenv("PSVAE_BF16_XCD");  // tuning (read per call: tests flip it in-process)
         b.xcd_remap = e ? atoi(e) : 1;
     }
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 96 * 1024 ? lds : 96 * 1024));
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN, WM, WN, KS, D, STAGED, CT>), (int)(lds > 96 * 1024 ? lds : 96 * 1024)))
+        return attr_err;
     // more workgroups than CUs: one workgroup per CU at a time (co-resident workgroups thrash the shared L1, see
     // gemm_f32.hip); the request only has to exceed half the CU's LDS
     static const bool cap_on = getenv("PSVAE_BF16_CAP") != nullptr && atoi(getenv("PSVAE_BF16_CAP")) != 0;  // measured: slower here

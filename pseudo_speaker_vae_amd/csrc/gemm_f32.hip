@@ -573,13 +573,9 @@ __global__ __launch_bounds__(64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS) vo
 
 template <int C0>
 static hipError_t launch_persistent(const GemmBatch& b, size_t lds, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<C0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&gemm_persistent_kernel<C0>), 160 * 1024))
+        return attr_err;
     constexpr int NT = 64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS;
     hipLaunchKernelGGL((gemm_persistent_kernel<C0>), dim3(256), dim3(NT), lds, stream, b);
     return hipGetLastError();
@@ -751,17 +747,13 @@ static size_t lds_bytes(const Cfg& c) {
     return (size_t)(c.KS * BM * (BN + 4) + c.KS * BM + 16) * sizeof(float);
 }
 
-// the dynamic-LDS limit of a kernel is raised once per process; std::call_once makes that safe from any thread
+// the dynamic-LDS limit of a kernel is raised once per (kernel, device): lds_opt_in (psvae_common.h), safe from any thread
 // (the library keeps no other mutable state per kernel: SURVEY 8b threading contract)
 template <int C0, int C1, bool S2 = false>
 static hipError_t launch_pair(const GemmBatch& b, size_t lds, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1, S2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&gemm_grouped_kernel<C0, C1, S2>), 160 * 1024))
+        return attr_err;
     constexpr int NT = 64 * CfgT<C0>::WM * CfgT<C0>::WN * CfgT<C0>::KS;
     hipLaunchKernelGGL((gemm_grouped_kernel<C0, C1, S2>), dim3(b.total_tiles), dim3(NT), lds, stream, b);
     return hipGetLastError();

@@ -15,7 +15,6 @@
 //   logits = W2 relu(W1 z + b1) + b2          (latent_classifier.py:30-40; or logits = W1 z + b1 when hidden == 0)
 //   grad   = d/dz [ log_softmax(logits)[target] - 0.5 |z|^2 ]                      (inference.py:56-93)
 //   z     += 0.5 s^2 grad + s w noise                                              (inference.py:97)
-#include <mutex>
 
 #include "psvae_common.h"
 
@@ -506,13 +505,9 @@ static hipError_t launch_langevin_mfma_lds(int64_t N, int C, const float* W1, co
                                            int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
                                            float* history, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * 4 * ZB * 64 * HB + LV_MAXC * 16 * HB + 16 * HB + LV_MAXC) * sizeof(float);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&langevin_mfma_lds_kernel<ZB, HB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&langevin_mfma_lds_kernel<ZB, HB>), 160 * 1024))
+        return attr_err;
     const int64_t groups = (N + 15) / 16, wgs = (groups + 7) / 8;
     const int per_cu = (int)((160 * 1024) / lds) >= 2 ? 2 : 1;
     const int grid = (int)(wgs < 256 * per_cu ? wgs : 256 * per_cu);  // persistent: every workgroup walks its row groups
@@ -559,12 +554,10 @@ hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1,
     const int grid = (int)((N + 255) / 256);
 #define PSVAE_LV(ZD)                                                                                                   \
     case ZD: {                                                                                                         \
-        static bool done = false;                                                                                      \
-        if (!done && lds > 48 * 1024) {                                                                                \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&langevin_kernel<ZD>),                   \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+        static std::atomic<unsigned long long> lds_ok{0}; /* per device: psvae_common.h lds_opt_in */                 \
+        if (lds > 48 * 1024) {                                                                                         \
+            hipError_t ea = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&langevin_kernel<ZD>), 160 * 1024);       \
             if (ea != hipSuccess) return ea;                                                                           \
-            done = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL(langevin_kernel<ZD>, dim3(grid), dim3(256), lds, s, N, hidden, C, W1, b1, W2, b2, z, target, \
                            step_size, noise_weight, num_steps, noises, seed, offset, history);                         \

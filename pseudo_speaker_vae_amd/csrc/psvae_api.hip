@@ -195,7 +195,7 @@ const char* psvae_strerror(int code) {
         case PSVAE_ERR_SHAPE: return "psvae: non-positive or unsupported dimension";
         case PSVAE_ERR_ALIGN: return "psvae: pointer is not 16-byte aligned";
         case PSVAE_ERR_ARG: return "psvae: bad enum / flag / phase argument";
-        case PSVAE_ERR_STATE: return "psvae: plan used in the wrong state";
+        case PSVAE_ERR_STATE: return "psvae: call not valid in this state (tuning under capture; a backward whose forward took another path)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "psvae: unknown error";
     }
 }

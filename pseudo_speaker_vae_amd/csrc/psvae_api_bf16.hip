@@ -97,6 +97,9 @@ BfScratch carve_bf(void* base, int64_t B, int64_t D, int64_t Z) {
 }
 
 thread_local int t_bf_launches = 0;  // launches of this thread's current / last bf16 pass
+// which path (row chains or a launch per layer) this thread's last forward took, and on which scratch / shape
+struct FwdPath { const void* scratch; int B, D, Z; bool chain; };
+thread_local FwdPath t_fwd_path = {nullptr, 0, 0, 0, false};
 
 inline GemmDescBf bdesc(int M, int N, int K, const u16* A, int lda, const u16* B, int ldb) {
     GemmDescBf d{};
@@ -146,8 +149,16 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     weight_dims(D, Z, wo, wi);
 
     int n_recon = sc.n_recon_max;  // backward-only call: every slot (the forward-only call zeroed the unused ones)
-    // B >= 2048: each 3-layer MLP as ONE launch over 32/64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder
+    // B >= 64 on the chain shapes (chain_fwd_ok; PSVAE_BF16_NO_CHAIN / PSVAE_BF16_CHAIN_MIN move it): each 3-layer MLP as
+    // ONE launch over 32/64-row tiles (chain_bf16.hip) -- encoders, reparameterisation, decoder.  The switch is read from
+    // the environment per call (tests flip it in-process); ONE decision serves both halves of this call, and a
+    // backward-only call checks it against what the forward-only call on the same scratch took (the two halves share
+    // activation and pack buffers that only the matching path writes): a mismatch is PSVAE_ERR_STATE, not garbage.
     const bool chain = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
+    if (fwd) t_fwd_path = {scratch, B, D, Z, chain};
+    else if (t_fwd_path.scratch == scratch && t_fwd_path.B == B && t_fwd_path.D == D && t_fwd_path.Z == Z &&
+             t_fwd_path.chain != chain)
+        return PSVAE_ERR_STATE;
     if ((normalize || cos_loss) && !chain) return PSVAE_ERR_SHAPE;  // the loss variants exist on the row-chain path only
     if (fwd) {
     if (chain) {  // (the chains read fp32 x and their own weight packs; x -> bf16 and the one-hot matrix, which only the weight
@@ -272,7 +283,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     // backward: wgrad  dW[o][i] = sum_b dY[b][o] X[b][i]   (A = dY [B,out], B = X [B,in]: both batch-major, read transposed
     //                                                       out of the staged LDS tiles; fp32 out, colsum = db)
     //           dgrad  dX[b][i] = sum_o dY[b][o] W^T[i][o]  (A = dY [B,out], B = W^T [in,out], masked, bf16 out)
-    const bool chain_bwd = chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D);
+    const bool chain_bwd = chain;  // the forward's decision (see above)
     int S = bf_wgrad_split(B);
     if (chain_bwd && !getenv("PSVAE_BF16_WGRAD_S")) {
         // all weight gradients share ONE launch there: cut the batch so that its 128x128 tiles make two rounds of workgroups

@@ -3,12 +3,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/psvae.h"
 
 namespace psvae {
 
 constexpr int H = PSVAE_HIDDEN;
 constexpr int WAVE = 64;
+
+// Raise a kernel's dynamic-LDS limit (> 64 KB needs the opt-in) once per (kernel, DEVICE): the attribute belongs to the
+// device that is current at the call, so a process that drives several devices -- psvae.h allows calls from several
+// host threads, one stream each -- opts every one of them in.  `done` is the call site's static bit mask over device
+// ordinals; a failure is returned and NOT cached (the next call tries again); racing first calls both set the
+// attribute, which is idempotent.  No other mutable state per kernel (SURVEY 8b threading contract).
+static inline hipError_t lds_opt_in(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

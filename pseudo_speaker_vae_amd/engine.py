@@ -267,12 +267,27 @@ class TrainEngine:
         self.adam_state[:8].copy_(b)
 
     def scheduler_step(self, epoch: Optional[int] = None) -> float:
-        """CosineAnnealingLR stepped once per epoch (lightning.py:206-213, 'interval': 'epoch'): closed form
-        eta_min + (base_lr - eta_min) (1 + cos(pi t / T_max)) / 2.  Without a scheduler the rate stays base_lr."""
-        self.epoch = self.epoch + 1 if epoch is None else int(epoch)
-        if self.scheduler:
-            T, eta_min = self.scheduler["T_max"], self.scheduler.get("eta_min", 0.0)
-            self._write_lr(eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * self.epoch / T)) / 2)
+        """CosineAnnealingLR stepped once per epoch (lightning.py:206-213, 'interval': 'epoch').  Stepped without an
+        argument it follows torch's RECURSIVE form (torch.optim.lr_scheduler.CosineAnnealingLR.get_lr), so the rate
+        equals torch's at every epoch -- past T_max too (T_max comes from hparams['scheduler'] and may be smaller than
+        max_epochs), where the recursion and the closed form part ways; with an explicit `epoch` it jumps there by the
+        closed form eta_min + (base_lr - eta_min) (1 + cos(pi t / T_max)) / 2, as torch's `step(epoch)` does.
+        Without a scheduler the rate stays base_lr."""
+        if not self.scheduler:
+            self.epoch = self.epoch + 1 if epoch is None else int(epoch)
+            return self.lr
+        T, eta_min = self.scheduler["T_max"], self.scheduler.get("eta_min", 0.0)
+        if epoch is not None:
+            self.epoch = int(epoch)
+            lr = eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * self.epoch / T)) / 2
+        else:
+            self.epoch += 1
+            t, cur = self.epoch, self.lr
+            if (t - 1 - T) % (2 * T) == 0:
+                lr = cur + (self.base_lr - eta_min) * (1 - math.cos(math.pi / T)) / 2
+            else:
+                lr = (1 + math.cos(math.pi * t / T)) / (1 + math.cos(math.pi * (t - 1) / T)) * (cur - eta_min) + eta_min
+        self._write_lr(lr)
         return self.lr
 
     def optimizer_step(self, lr: Optional[float] = None):
@@ -288,20 +303,38 @@ class TrainEngine:
         return struct.unpack("<q", self.adam_state[8:16].cpu().numpy().tobytes())[0]
 
     # ------------------------------------------------------------------------------------------
+    def _persistent_state(self):
+        """everything a step or an optimizer step changes and a later step reads"""
+        return [t for t in (self.flat_params, self.flat_params_t, self.exp_avg, self.exp_avg_sq, self.adam_state,
+                            self.rng_state) if t is not None]
+
     def _warm(self, body, n=2):
+        """Run `body` n times outside capture (hipFuncSetAttribute, lazy module load, communicator setup) WITHOUT
+        leaving a trace: parameters, k-major copies, Adam moments, the device-side {lr, step} and the Philox state are
+        snapshotted before and restored after, so capturing never trains the model, never advances bias correction and
+        never consumes epsilon -- the first replay is step 1 from the state the caller captured in.  Gradients, outputs
+        and the loss scalars are a step's outputs and hold the warm-up's values until the first replay."""
+        torch.cuda.synchronize(self.device)
+        state = self._persistent_state()
+        saved = [t.clone() for t in state]
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(n):  # warm-up outside capture (hipFuncSetAttribute, lazy module load, communicator setup)
+            for _ in range(n):
                 body()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        for t, s in zip(state, saved):
+            t.copy_(s)
         torch.cuda.synchronize(self.device)
 
     def capture(self, x: torch.Tensor, with_adam: bool = False):
         """Capture forward + ELBO + backward (and, with_adam, the optimizer step: single GPU only -- with a process
         group the all-reduce sits between them) into one HIP graph.  The captured step reads its batch from a static
         buffer (`self.static_x`) and its epsilon stream from the device-resident Philox state, which the graph itself
-        advances, so every replay draws fresh noise; Adam's step counter is device-resident too."""
+        advances, so every replay draws fresh noise; Adam's step counter is device-resident too.  Capturing leaves
+        the model, the optimizer state and the Philox state as they were (`_warm`): N replays == N eager iterations
+        from the same starting point."""
         if with_adam and self.averager is not None:
             raise _ffi.PsvaeError("capture(with_adam=True) is the single-GPU form: the all-reduce comes between")
         self.static_x = x.detach().clone()

@@ -58,20 +58,18 @@ def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group,
     ref = TrainEngine(D, Z, B, device=DEV, seed=7, beta=0.9)
     eng = TrainEngine(D, Z, B, device=DEV, seed=7, beta=0.9, process_group=nccl_group)
     assert eng.world == 1 and eng.averager is not None and eng.averager.backend == "nccl"
-    warm = 0
     if mode == "eager_split":
         step = lambda: eng.forward_backward(x)
     elif mode == "graph_then_allreduce":
         eng.capture(x)
-        warm, step = 2, eng.replay
+        step = eng.replay
     elif mode == "two_graphs":
         eng.capture_ddp(x)
-        warm, step = 2, eng.replay_ddp
+        step = eng.replay_ddp
     else:
         eng.capture_with_collective(x, overlap=(mode == "in_graph_overlap"))
-        warm, step = 3, eng.replay
-    for _ in range(warm):  # the captures warm up with real steps: keep the reference's Philox state in step
-        ref.forward_backward(x)
+        step = eng.replay
+    # (the captures' warm-up steps leave no trace: the first replay is step 1, same Philox position as `ref`)
     for it in range(3):
         ref.forward_backward(x)
         step()
@@ -92,14 +90,11 @@ def test_one_rank_rccl_bf16_engine_matches_the_engine_without_a_group(nccl_group
     gender, age = torch.randint(-1, 3, (B,), generator=g), torch.randint(-1, 3, (B,), generator=g)
     ref.set_labels(gender, age)
     eng.set_labels(gender, age)
-    warm = 0
     if mode == "eager":
         step = lambda: eng.forward_backward(x)
     else:
         eng.capture(x)
-        warm, step = 2, eng.replay
-    for _ in range(warm):
-        ref.forward_backward(x)
+        step = eng.replay
     for it in range(3):
         ref.forward_backward(x)
         step()
@@ -142,7 +137,7 @@ def _two_rank_worker(rank, world, port, q):
         torch.cuda.synchronize()
         out["eager_grads"] = eng.flat_grads.cpu().clone()
         out["eager_eps"] = eng.ws.acts["eps"].cpu().clone()
-        eng.capture(xs)                                # 2 warm-up steps (local) + capture
+        eng.capture(xs)                                # (warm-up steps are local and leave no trace) + capture
         eng.replay()                                   # captured step, then ONE all-reduce of the flat buffer
         torch.cuda.synchronize()
         out["graph_grads"] = eng.flat_grads.cpu().clone()
@@ -188,8 +183,7 @@ def test_two_ranks_on_one_gpu_over_gloo_average_like_one_full_batch_engine():
         assert_close(res[0]["eager_grads"][o:o + n], full.flat_grads[o:o + n].cpu(), 2e-5, "mean of shard grads " + k)
     lo = lay.loss_offset
     assert_close(res[0]["eager_grads"][lo:lo + 3], full.flat_grads[lo:lo + 3].cpu(), 2e-6, "averaged loss scalars")
-    for _ in range(3):          # the ranks' capture ran 2 warm-ups + the replayed step = full-batch steps 2..4
-        full.forward_backward(x)
+    full.forward_backward(x)    # the ranks' replayed step = full-batch step 2 (capturing consumed no epsilon)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([res[0]["graph_eps"], res[1]["graph_eps"]]), full.ws.acts["eps"].cpu())
     for k, (o, s) in zip(full.keys, zip(lay.offsets, lay.shapes)):

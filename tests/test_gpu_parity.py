@@ -220,9 +220,26 @@ def test_fused_train_step_matches_unfused_path_and_oracle(ops, D, Z, B):
     assert_close(outs[0].cpu(), ref["x_hat"], 5e-6, "x_hat")
     assert_close(loss3.cpu(), ref["loss3"], 5e-6, "loss3")
     masks = {k: (ws.acts[k] > 0).cpu() for k in MASK_KEYS}
-    if all(torch.equal(masks[k], ref["masks"][k]) for k in MASK_KEYS):  # (a ReLU-kink flip moves a whole dW row)
-        for k, g in zip(O.PARAM_KEYS, grads):
+    # A ReLU-kink flip between the two paths (an activation within rounding of 0) moves the gradient of the flipped
+    # layer and of everything upstream of it by O(1/B): compare every parameter whose gradient no flipped mask feeds
+    # into, bound the flips as check_masks does, and make a partial comparison VISIBLE instead of skipping.
+    flips = {k: int((masks[k] != ref["masks"][k]).sum()) for k in MASK_KEYS}
+    for k, n in flips.items():
+        assert n <= max(2, 2e-5 * masks[k].numel()), f"{k}: {n} ReLU masks differ between the fused and the unfused path"
+    feeds = {"decoder.4": (), "decoder.2": ("d2",), "decoder.0": ("d2", "d1"),
+             "encoder_mu.4": ("d2", "d1"), "encoder_mu.2": ("d2", "d1", "h2m"), "encoder_mu.0": ("d2", "d1", "h2m", "h1m"),
+             "encoder_sigma.4": ("d2", "d1"), "encoder_sigma.2": ("d2", "d1", "h2s"),
+             "encoder_sigma.0": ("d2", "d1", "h2s", "h1s")}
+    compared = 0
+    for k, g in zip(O.PARAM_KEYS, grads):
+        if not any(flips[m] for m in feeds[k.rsplit(".", 1)[0]]):
             assert_close(g.cpu(), ref["grads"][k], 2e-5, "fused vs unfused grad " + k)
+            compared += 1
+    assert compared >= 2  # decoder.4's weight and bias gradients depend on no mask
+    if compared < len(O.PARAM_KEYS):
+        import warnings
+        warnings.warn(f"fused vs unfused (D={D}, Z={Z}, B={B}): ReLU-kink flips {flips}; {compared} of "
+                      f"{len(O.PARAM_KEYS)} gradient tensors compared at 2e-5, the rest against the oracle only")
     losses, ograds, oacts, _ = O.train_step(p, x, eps, 0.9, go=go, masks=masks)
     check_masks(masks, oacts)
     for i, k in enumerate(("total", "recon", "kl")):
