@@ -375,6 +375,76 @@ def bench_langevin(args, rk: Rank):
                                  "fp32 MFMA (one wavefront per 16 rows, four per SIMD); the rest is Philox / softmax / update VALU work"}}), flush=True)
 
 
+def bench_api_step(args, rk: Rank):
+    """The drop-in API path, as the reference's training script drives it through Lightning
+    (/root/reference/ps_vae/lightning.py:67-131, training.py:84): optimizer.zero_grad(); out = PseudoSpeakerVAE.
+    training_step((x, y), i); out["loss"].backward()  [; optimizer.step() with --with-adam: torch.optim.Adam, what
+    configure_optimizers returns].  Same shape and metric as the headline (cfg2), but every step goes through the
+    nn.Module / autograd surface instead of TrainEngine's replay loop; from the third step on the fused step runs as one
+    captured HIP graph (pseudo_speaker_vae_amd/api_graph.py; PSVAE_API_GRAPH=0 keeps it eager)."""
+    from pseudo_speaker_vae_amd.lightning import PseudoSpeakerVAE
+    if rk.world != 1:
+        raise SystemExit("[bench] --workload api-step is a one-GPU measurement (the N-GPU job is the train workload)")
+    dev = rk.dev
+    D, Z, B = args.input_dim, args.latent_dim, args.batch
+    torch.manual_seed(0)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), optimizer=dict(lr=1e-3), scheduler=dict(T_max=10)).to(dev)
+    opt = mod.configure_optimizers()["optimizer"]
+    plan = mod.model.tune_from_committed_plan(B)
+    g = torch.Generator().manual_seed(1234)
+    nbatch = 8  # the loop walks a few resident batches: every step copies a different x into the step's input
+    xs = [torch.randn(B, D, generator=g).to(dev) for _ in range(nbatch)]
+    y = torch.zeros(B, dtype=torch.long, device=dev)
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        out = mod.training_step((xs[i % nbatch], y), i)
+        out["loss"].backward()
+        if args.with_adam:
+            opt.step()
+    prewarm(step, args, rk)
+    wall, dev_ms = timed(rk, step, args.steps, args.warmup)
+    graphs = mod.model._scratch_cache.graphs
+    loss = [float(mod.logged[k]) for k in ("train_loss", "train_recon_loss", "train_kl_loss")]
+    fpe = flop_per_embedding(D, Z)
+    step_s_dev = dev_ms / 1e3 / args.steps
+    achieved = fpe * B / step_s_dev / 1e12
+    slot = next(iter(graphs.slots.values()), None)
+    print(json.dumps({
+        "metric": "speaker-embeddings/sec (fwd+bwd)", "value": round(B * args.steps / wall, 1),
+        "unit": "speaker-embeddings/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{config_label(D, Z, B, 'f32', False)} through the drop-in API: optimizer.zero_grad + "
+                               f"PseudoSpeakerVAE.training_step + loss.backward(){' + torch Adam.step' if args.with_adam else ''}"
+                               f" per step (lightning.py:67-131), d_in={D} z={Z} hidden=512, batch={B}, fp32",
+                   "launch": "one captured HIP graph per step behind the autograd Function" if graphs.served
+                   else "eager launches from the autograd Function",
+                   "graph_steps_served": graphs.served, "launches_per_step": slot.launches if slot else None,
+                   "launch_plan": plan, "n_gpus": 1, "parallelism": "dp1", "prewarm_ms": args.prewarm_ms},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "flop_per_embedding": fpe,
+                     "device_ms_per_step": round(step_s_dev * 1e3, 5),
+                     "scope": "whole API step incl. the batch copy, the loss copy and the gradient scale launch, "
+                              "HIP events on the launch stream"},
+        "loss": [round(v, 6) for v in loss]}), flush=True)
+
+
+def prewarm(step, args, rk: Rank):
+    """untimed, BEFORE the W warm-up steps: run the step for --prewarm-ms of wall time so that the timed region sees the
+    clocks and caches of a training run in progress, not of a GPU that was idle a millisecond ago (a 20-step run from
+    idle measured 5 % slower than the same loop after 40 ms of work).  Reported as config.prewarm_ms; 0 switches it off."""
+    if args.prewarm_ms <= 0 or rk.stub:
+        return
+    t0 = time.perf_counter()
+    i = 0
+    while (time.perf_counter() - t0) * 1e3 < args.prewarm_ms:
+        for _ in range(50):
+            step(i)
+            i += 1
+        torch.cuda.synchronize(rk.dev)
+
+
 def committed_traffic(D, Z, B, dtype, plan):
     """HBM-side bytes per step from the committed rocprofv3 PMC passes -- reported with its provenance, and only when
     the committed passes were taken on this shape; never presented as measured in this run"""
@@ -410,6 +480,10 @@ def run_rank(args) -> int:
         return 0
     if args.workload == "langevin":
         bench_langevin(args, rk)
+        rk.close()
+        return 0
+    if args.workload == "api-step":
+        bench_api_step(args, rk)
         rk.close()
         return 0
 
@@ -477,6 +551,7 @@ def run_rank(args) -> int:
             if args.with_adam:
                 eng.optimizer_step()
 
+    prewarm(step, args, rk)
     wall, dev_ms = timed(rk, step, args.steps, args.warmup)
     loss = eng.loss3.detach().cpu().tolist()
 
@@ -501,7 +576,8 @@ def run_rank(args) -> int:
                                    f"batch={B}/GPU, global_batch={B * world}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
                        "launch": mode, "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
-                       "launch_plan": plan, "launches_per_step": eng.launches_per_step()},
+                       "launch_plan": plan, "launches_per_step": eng.launches_per_step(),
+                       "prewarm_ms": args.prewarm_ms},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
@@ -531,9 +607,13 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = config 3 arithmetic (bf16 MFMA operands, fp32 accumulate and master weights)")
     ap.add_argument("--cond", action="store_true", help="config 3: one-hot gender+age conditioning")
-    ap.add_argument("--workload", choices=["train", "decode", "langevin"], default="train",
+    ap.add_argument("--workload", choices=["train", "decode", "langevin", "api-step"], default="train",
                     help="train = cfg2 (headline); decode = cfg5 decode-only sampling; langevin = cfg5 conditional "
-                         "sampling (Langevin chain + decode); --samples rows in total")
+                         "sampling (Langevin chain + decode); --samples rows in total; api-step = the train shape "
+                         "through PseudoSpeakerVAE.training_step + loss.backward() (the drop-in API path)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed: run the step for this long before the W warm-up steps (clocks / caches of a run in "
+                         "progress); 0 = off")
     ap.add_argument("--samples", type=int, default=1_000_000, help="decode / langevin workloads: rows over all GPUs")
     ap.add_argument("--langevin-steps", type=int, default=100, help="Langevin steps per row (inference.py:34 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

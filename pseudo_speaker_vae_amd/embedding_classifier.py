@@ -28,8 +28,8 @@ def consistency_ce_raw(x_hat, y, params, grad_scale: float = 1.0, want_param_gra
     B, D = x_hat.shape
     ps = [p.detach().float().contiguous() for p in params]
     hidden, C = ps[0].shape[0], ps[4].shape[0]
-    from .latent_classifier import check_labels
-    check_labels(y, C, "EmbeddingClassifier (consistency) cross entropy")
+    from .latent_classifier import label_watch
+    label_watch.before(y, C, "EmbeddingClassifier (consistency) cross entropy")
     lib = _ffi.lib()
     scratch = torch.empty(int(lib.psvae_consistency_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=x_hat.device)
     loss2 = torch.empty(2, dtype=torch.float32, device=x_hat.device)
@@ -43,6 +43,7 @@ def consistency_ce_raw(x_hat, y, params, grad_scale: float = 1.0, want_param_gra
     _ffi.check(lib.psvae_consistency_ce_f32(
         B, D, hidden, C, _ffi.ptr(x_hat), _ffi.ptr(y), *[_ffi.ptr(p) for p in ps], float(grad_scale), _ffi.ptr(loss2),
         _ffi.ptr(g_x), pg, _ffi.ptr(scratch), _ffi.stream_ptr()), "consistency_ce")
+    label_watch.after(loss2[0], y, C, "EmbeddingClassifier (consistency) cross entropy")
     return loss2, g_x, grads
 
 

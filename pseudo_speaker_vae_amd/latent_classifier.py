@@ -15,16 +15,54 @@ import torch.nn as nn
 from . import _ffi
 
 
-def check_labels(y: torch.Tensor, C: int, what: str = "classifier") -> None:
-    """The reference's F.cross_entropy raises on a label outside [0, C) (lightning.py:79 is fed the raw label maps, whose
-    "unknown" is -1: utils.py:103,120,136).  Same here, by default: one small device reduction + host read per step.
-    PSVAE_CHECK_LABELS=0 skips it; the fused kernels then poison the loss with NaN for such rows instead."""
-    import os
-    if os.environ.get("PSVAE_CHECK_LABELS", "1") == "0":
-        return
-    if bool(((y < 0) | (y >= C)).any()):
-        bad = y[(y < 0) | (y >= C)][:4].tolist()
-        raise _ffi.PsvaeError(f"{what}: label out of range [0, {C}): {bad} (map unknown labels out of the batch first)")
+class LabelWatch:
+    """Out-of-range labels without a host sync per step.
+
+    The reference's F.cross_entropy raises on a label outside [0, C) (lightning.py:79 is fed the raw label maps, whose
+    "unknown" is -1: utils.py:103,120,136) -- on a GPU as an asynchronous device-side assert.  The fused kernels turn such
+    a row's loss term into NaN, so the step's loss IS the device-side error flag.  This watch folds every step's loss
+    into a sticky accumulator on the device (torch.maximum propagates NaN: one tiny launch, no sync) and reads it back
+    every `every` steps (`PSVAE_CHECK_LABELS_EVERY`, default 50) -- and on the very first step, where a wrongly mapped
+    dataset shows at once.  A poisoned accumulator raises: with the offending labels when the current batch has them,
+    else naming the window.  `PSVAE_CHECK_LABELS=sync` checks every batch before its launch (a device reduction and a
+    host read per step: the round-2 behaviour); `PSVAE_CHECK_LABELS=0` switches the watch off."""
+
+    def __init__(self):
+        import os
+        self.mode = os.environ.get("PSVAE_CHECK_LABELS", "1")
+        self.every = max(1, int(os.environ.get("PSVAE_CHECK_LABELS_EVERY", "50")))
+        self.acc = {}      # (device, head) -> sticky accumulator
+        self.calls = {}
+
+    @staticmethod
+    def _raise_if_bad(y, C, what):
+        bad_rows = (y < 0) | (y >= C)
+        if bool(bad_rows.any()):
+            raise _ffi.PsvaeError(f"{what}: label out of range [0, {C}): {y[bad_rows][:4].tolist()} "
+                                  "(map unknown labels out of the batch first)")
+
+    def before(self, y: torch.Tensor, C: int, what: str) -> None:
+        if self.mode == "sync" or (self.mode != "0" and self.calls.get((y.device, what), 0) == 0):
+            self._raise_if_bad(y, C, what)
+
+    def after(self, loss: torch.Tensor, y: torch.Tensor, C: int, what: str) -> None:
+        """`loss`: a device tensor that is NaN iff a row of this step had a label outside [0, C) (or the step diverged)"""
+        if self.mode in ("0", "sync"):
+            return
+        dev = (y.device, what)
+        acc = self.acc.get(dev)
+        if acc is None:
+            acc = self.acc[dev] = torch.zeros((), dtype=torch.float32, device=y.device)
+        torch.maximum(acc, loss.detach().reshape(()), out=acc)
+        n = self.calls[dev] = self.calls.get(dev, 0) + 1
+        if n % self.every == 0 and bool(torch.isnan(acc)):
+            acc.zero_()
+            self._raise_if_bad(y, C, what)
+            raise _ffi.PsvaeError(f"{what}: the loss became NaN within the last {self.every} steps: a label outside "
+                                  f"[0, {C}) was fed (map unknown labels out of the batch first), or training diverged")
+
+
+label_watch = LabelWatch()
 
 
 def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
@@ -37,7 +75,7 @@ def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
     W1, b1 = ps[0], ps[1]
     W2, b2 = (ps[2], ps[3]) if hidden else (None, None)
     C = (W2 if hidden else W1).shape[0]
-    check_labels(y, C, "LatentClassifier cross entropy")
+    label_watch.before(y, C, "LatentClassifier cross entropy")
     lib = _ffi.lib()
     scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, C)), dtype=torch.uint8, device=z.device)
     loss2 = torch.empty(2, dtype=torch.float32, device=z.device)
@@ -48,6 +86,7 @@ def classifier_ce_raw(z, y, hidden, params, grad_scale: float = 1.0):
         float(grad_scale), _ffi.ptr(loss2), _ffi.ptr(g_z), _ffi.ptr(grads[0]), _ffi.ptr(grads[1]),
         _ffi.ptr(grads[2]) if hidden else None, _ffi.ptr(grads[3]) if hidden else None, _ffi.ptr(scratch),
         _ffi.stream_ptr()), "classifier_ce")
+    label_watch.after(loss2[0], y, C, "LatentClassifier cross entropy")
     return loss2, g_z, grads
 
 

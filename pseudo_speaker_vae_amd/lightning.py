@@ -147,11 +147,12 @@ class PseudoSpeakerVAE(_Base):
     def _step(self, batch, prefix: str):
         x, y = batch
         log_kw = dict(sync_dist=True) if prefix == "train" else dict(batch_size=x.size(0), sync_dist=True)
-        vae_trainable = any(p.requires_grad for p in self.model.parameters())
+        vae_trainable = any(p.requires_grad for p in self.model.ordered_params())  # (cached list: no module walk)
         cons = self.consistency_classifier
         if cons is None and self.classifier is None and (vae_trainable or not torch.is_grad_enabled()):
-            # fused: forward + ELBO on the GPU, one autograd node (lightning.py:110-124)
-            total, recon, kl, _, _, _ = self.model.elbo_step(x, self.kl_loss_weight, self.use_cos_loss)
+            # fused: forward + ELBO on the GPU, one autograd node (lightning.py:110-124); from the third step of a batch
+            # shape on, one captured HIP graph (api_graph.py).  Only the losses are needed here: outputs=False
+            total, recon, kl, _, _, _ = self.model.elbo_step(x, self.kl_loss_weight, self.use_cos_loss, outputs=False)
         elif (x.is_cuda and not isinstance(y, dict) and (vae_trainable or not torch.is_grad_enabled())
               and (self.classifier is None or (not self.multilabel and self.classifier.fused_params() is not None))
               and (cons is None or cons.fused_ok())):

@@ -14,7 +14,7 @@ import torch
 import torch.distributed
 import torch.nn as nn
 
-from . import _ffi, ops
+from . import _ffi, api_graph, ops
 
 HIDDEN = _ffi.HIDDEN
 
@@ -27,6 +27,7 @@ class _Buffers:
         self._scratch: Dict[tuple, torch.Tensor] = {}
         self.keep_last = False   # tests: keep the most recent call's context alive (its saved activations)
         self._last = None
+        self.graphs = api_graph.GraphSteps()   # captured fused steps for the shapes training_step keeps seeing
 
     def remember(self, c):
         if self.keep_last:
@@ -199,13 +200,30 @@ class ELBOStepFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eps, meta, *params):
-        seed, offset, flags, buffers, beta, cond_tensors = meta
+        seed, offset, flags, buffers, beta, cond_tensors = meta[:6]
+        world, want_outputs = meta[6:8] if len(meta) > 6 else (1, True)
+        live_params = params
         params = [p.detach() for p in params]
         ncond = 3 if cond_tensors is not None else 0
         vae_params = params[:_ffi.NPARAM]
         if ncond:
             cond_tensors = (params[_ffi.NPARAM:], cond_tensors[1], cond_tensors[2])
         ctx.fused_grads = None
+        ctx.slot = None
+        if (_FUSED_AUTOGRAD and eps is None and not ncond and all(ctx.needs_input_grad[3:]) and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == params[0].shape[1]):
+            # steady state of a training loop: the whole fused step as ONE captured HIP graph on static buffers
+            # (api_graph.py); returns None whenever the call is not one it may serve, and the eager path below runs
+            slot = buffers.graphs.lookup(x, params[4].shape[0], flags, beta, live_params, world)
+            if slot is not None:
+                token = object()
+                loss3 = slot.run(x.detach(), seed, offset, token)
+                ctx.slot, ctx.token, ctx.guard = slot, token, api_graph._Pending(slot, token)
+                buffers.remember(slot)
+                total, recon, kl = loss3[0], loss3[1], loss3[2]
+                outs = tuple(t.clone() for t in slot.outs) if want_outputs else (None, None, None)
+                ctx.mark_non_differentiable(recon, kl, *(t for t in outs if t is not None))
+                return (total, recon, kl, *outs)
         if any(ctx.needs_input_grad[3:]) and _FUSED_AUTOGRAD:
             # parameters want gradients: run the fused train step now (forward + ELBO + backward with d(total) = 1; every
             # loss variant, with or without the conditional tables) and hand the gradients out, scaled, in backward()
@@ -224,6 +242,12 @@ class ELBOStepFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, *_):
+        if ctx.slot is not None:  # graph path: the gradients wait, unscaled, in the slot's flat buffer
+            if ctx.slot.pending is not ctx.token:
+                raise _ffi.PsvaeError("backward of a fused step whose gradients are gone: it ran already, or another "
+                                      "step of the same shape has replaced them (PSVAE_API_GRAPH=0 keeps every step's "
+                                      "gradients in buffers of its own)")
+            return (None, None, None, *ctx.slot.scaled_grads(g_total.float()))
         if ctx.fused_grads is not None:  # gradients are linear in d(total): scale the precomputed ones on the device
             grads = ctx.fused_grads
             ctx.fused_grads = None
@@ -387,16 +411,19 @@ class VAEModel(nn.Module):
     def flags(self) -> int:
         return _ffi.NORMALIZE_DECODER if self.normalize_decoder else 0
 
+    def _rank_world(self) -> Tuple[int, int]:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(), torch.distributed.get_world_size()
+        return 0, 1
+
     def _next_rng(self, n_elems: int) -> Tuple[int, int]:
         """(seed, offset) of this call's epsilon stream: seed follows torch.manual_seed, the offset
         advances by the Philox blocks the call consumes, so successive forwards never reuse noise."""
         seed = torch.initial_seed() & ((1 << 64) - 1)
         nblk = (n_elems + 3) // 4
-        rank, world = 0, 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            # data-parallel ranks are usually seeded alike (Lightning's seed_everything): interleave their counter
-            # ranges by rank so that shards never share noise (rank r takes the r-th block range of each step)
-            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        # data-parallel ranks are usually seeded alike (Lightning's seed_everything): interleave their counter
+        # ranges by rank so that shards never share noise (rank r takes the r-th block range of each step)
+        rank, world = self._rank_world()
         off = self._philox_offset + rank * nblk
         self._philox_offset += world * nblk
         return seed, off
@@ -424,7 +451,17 @@ class VAEModel(nn.Module):
         grads = [torch.empty_like(t) for t in params]
         x = torch.randn(batch_size, self.input_dim, device=p0.device)
         loss3 = torch.empty(3, device=p0.device)
+        self._scratch_cache.graphs.invalidate()   # captured steps hold the plan they were captured under
         return ops.tune_train_step(ws, x, params, grads, ws.new_outputs(), loss3, iters=iters)
+
+    def tune_from_committed_plan(self, batch_size: int) -> Optional[str]:
+        """install the launch plan committed for this GPU model and (batch_size, input_dim, latent_dim), if there is one
+        (pseudo_speaker_vae_amd/launch_plans.json / $PSVAE_PLAN_CACHE; no measurement); returns its text or None"""
+        from types import SimpleNamespace
+        shape = SimpleNamespace(B=batch_size, D=self.input_dim, Z=self.latent_dim, device=self.encoder_mu[0].weight.device,
+                                dims=_ffi.Dims(batch_size, self.input_dim, self.latent_dim))
+        self._scratch_cache.graphs.invalidate()
+        return ops.load_committed_plan(shape)
 
     def elbo_heads_step(self, x: torch.Tensor, y: torch.Tensor, classifier=None, consistency=None, beta: float = 1.0,
                         classifier_weight: float = 1.0, consistency_weight: float = 1.0, use_cos_loss: bool = False,
@@ -463,11 +500,15 @@ class VAEModel(nn.Module):
         return ELBOTermsFunction.apply(x_hat, mu, log_sigma, x, bool(use_cos_loss), self._scratch_cache)
 
     def elbo_step(self, x: torch.Tensor, beta: float = 1.0, use_cos_loss: bool = False,
-                  eps: Optional[torch.Tensor] = None):
-        """fused forward + ELBO (lightning.py:110-124): returns (total, recon, kl, x_hat, mu, logvar)."""
+                  eps: Optional[torch.Tensor] = None, outputs: bool = True):
+        """fused forward + ELBO (lightning.py:110-124): returns (total, recon, kl, x_hat, mu, logvar).  A training loop
+        that keeps calling this with one batch shape is served, from its third call on, by a captured HIP graph of the
+        whole fused step (api_graph.py: same numbers, same epsilon stream, ~1/2 of the host time); `outputs=False`
+        (what training_step passes: it only needs the losses) lets that path skip the copies of x_hat / mu / logvar
+        and returns None for them."""
         seed, off = self._next_rng(x.shape[0] * self.latent_dim)
         flags = self.flags | (_ffi.COS_LOSS if use_cos_loss else 0)
-        meta = (seed, off, flags, self._scratch_cache, float(beta), None)
+        meta = (seed, off, flags, self._scratch_cache, float(beta), None, self._rank_world()[1], bool(outputs))
         return ELBOStepFunction.apply(x, eps, meta, *self.ordered_params())
 
 

@@ -709,3 +709,112 @@ def test_training_step_consistency_fused_node_equals_separate_nodes(with_clf):
         v = mod.validation_step((x, y), 0)
     assert torch.isfinite(v["loss"]) and all(p.grad is None for p in mod.parameters())
     assert "val_consistency_loss" in mod.logged and ("val_classifier_loss" in mod.logged) == with_clf
+
+
+def _twin_modules(D, Z, seed, **hp):
+    """two PseudoSpeakerVAE with the same weights: `g` may use the captured-graph step, `e` never does"""
+    from ps_vae.lightning import PseudoSpeakerVAE
+    torch.manual_seed(seed)
+    g = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), **hp).to(DEV)
+    e = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), **hp).to(DEV)
+    e.load_state_dict(g.state_dict())
+    e.model._scratch_cache.graphs.enabled = False
+    g.model._scratch_cache.graphs.enabled = True
+    return g, e
+
+
+def test_training_step_graph_path_equals_eager_path_step_by_step_and_matches_oracle():
+    """The drop-in step as Lightning drives it (zero_grad, training_step, loss.backward, optimizer.step): from the third
+    step of a batch shape on it is ONE captured HIP graph on static buffers (api_graph.py).  Same kernels, same launch
+    plan, same Philox positions as the eager path: losses, gradients and the trained parameters must be bit-identical
+    step by step, and the last step must match the oracle at 1e-4."""
+    D, Z, B = 256, 64, 96
+    g, e = _twin_modules(D, Z, 5, kl_loss_weight=0.7)
+    og, oe = torch.optim.Adam(g.parameters(), lr=1e-3), torch.optim.Adam(e.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    y = torch.zeros(B, dtype=torch.long, device=DEV)
+    torch.manual_seed(77)
+    for it in range(7):
+        x = torch.randn(B, D, generator=gen)
+        xd = x.to(DEV)
+        if it == 5:
+            torch.manual_seed(78)                      # a new seed mid-run: the device-side Philox state must follow
+        p_before = {k: v.detach().cpu().clone() for k, v in zip(O.PARAM_KEYS, g.model.ordered_params())}
+        outs = []
+        for mod, opt in ((g, og), (e, oe)):
+            opt.zero_grad(set_to_none=True)
+            out = mod.training_step((xd, y), it)
+            out["loss"].backward()
+            outs.append(out["loss"].detach().clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), f"step {it}: loss"
+        assert torch.equal(g.logged["train_kl_loss"], e.logged["train_kl_loss"])
+        for k, a, b in zip(O.PARAM_KEYS, g.model.ordered_params(), e.model.ordered_params()):
+            assert torch.equal(a.grad, b.grad), f"step {it}: grad {k}"
+        og.step(); oe.step()
+    graphs = g.model._scratch_cache.graphs
+    assert graphs.served == 5 and e.model._scratch_cache.graphs.served == 0      # steps 2..6 ran as the graph
+    slot = next(iter(graphs.slots.values()))
+    assert slot.launches == 11                         # the fused step + the k-major weight copies it makes itself
+    for a, b in zip(g.model.ordered_params(), e.model.ordered_params()):
+        assert torch.equal(a, b)
+    # the last step against the oracle: epsilon and masks from the slot's static activations
+    eps = slot.acts["eps"].cpu()
+    assert_close(eps, O.philox_normal(B * Z, 78, 6 * (B * Z // 4)).reshape(B, Z), 1e-5, "graph path: device Philox stream")
+    masks = masks_of(slot.acts)
+    losses, grads, acts, _ = O.train_step(p_before, x, eps, 0.7, masks=masks)
+    check_masks(masks, acts)
+    assert abs(float(outs[0]) - float(losses["total"])) < REL_TOL
+    for k, q in zip(O.PARAM_KEYS, g.model.ordered_params()):
+        assert_close(q.grad.cpu(), grads[k], REL_TOL, "graph path grad " + k)
+
+
+def test_training_step_graph_path_steps_aside_when_its_buffers_are_still_in_use():
+    """the captured step owns ONE set of gradient buffers: a caller that keeps `.grad` alive across steps
+    (zero_grad(set_to_none=False), gradient accumulation) or runs two forwards before a backward must get the eager path
+    for those calls -- and the same numbers as a model that never uses the graph"""
+    D, Z, B = 128, 32, 64
+    g, e = _twin_modules(D, Z, 9)
+    xs = [torch.randn(B, D, device=DEV) for _ in range(8)]
+    y = torch.zeros(B, dtype=torch.long, device=DEV)
+    torch.manual_seed(5)
+
+    def same_grads(what):
+        torch.cuda.synchronize()
+        for k, a, b in zip(O.PARAM_KEYS, g.model.ordered_params(), e.model.ordered_params()):
+            assert torch.equal(a.grad, b.grad), f"{what}: grad {k}"
+
+    for it in range(4):                                # steps 0, 1 eager (warm-up), 2 and 3 on the graph
+        for mod in (g, e):
+            mod.zero_grad(set_to_none=True)
+            mod.training_step((xs[it], y), it)["loss"].backward()
+    same_grads("graph step")
+    served = g.model._scratch_cache.graphs.served
+    assert served == 2
+    # (1) .grad kept and zeroed in place: it aliases the slot's buffer, the next replay would overwrite it
+    for mod in (g, e):
+        mod.zero_grad(set_to_none=False)
+        mod.training_step((xs[4], y), 4)["loss"].backward()
+    same_grads("kept .grad")
+    assert g.model._scratch_cache.graphs.served == served
+    # (2) gradient accumulation over two micro-batches
+    for mod in (g, e):
+        mod.zero_grad(set_to_none=True)
+        mod.training_step((xs[5], y), 5)["loss"].backward()       # graph (nothing aliases)
+        (mod.training_step((xs[6], y), 6)["loss"] * 0.5).backward()  # .grad of micro-batch 1 lives in the slot: eager
+    same_grads("accumulation")
+    assert g.model._scratch_cache.graphs.served == served + 1
+    # (3) two forwards, then both backwards
+    for mod in (g, e):
+        mod.zero_grad(set_to_none=True)
+        l1 = mod.training_step((xs[7], y), 7)["loss"]
+        l2 = mod.training_step((xs[0], y), 8)["loss"]
+        l2.backward()
+        l1.backward()
+    same_grads("two forwards in flight")
+    # (4) a step whose gradients were consumed cannot be differentiated again
+    g.zero_grad(set_to_none=True)
+    l = g.training_step((xs[1], y), 9)["loss"]
+    l.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="gradients are gone"):
+        l.backward()

@@ -288,21 +288,46 @@ def test_scheduler_step_is_cosine_annealing():
 
 def test_label_out_of_range_is_reported_by_the_fused_heads():
     """ADVICE (round 1): y outside [0, C) -- e.g. the -1 "unknown" of the label maps -- must not train silently: the
-    reference's F.cross_entropy raises; the fused steps count such rows and the Python wrappers raise"""
-    from pseudo_speaker_vae_amd import _ffi
+    reference's F.cross_entropy raises (on a GPU: an asynchronous device-side assert).  The fused kernel turns such a row's
+    loss into NaN; the watch (latent_classifier.LabelWatch) checks the first batch before its launch, folds every later
+    step's loss into a sticky device flag WITHOUT a host sync, reads the flag every `every` steps and raises; `sync`
+    mode checks every batch up front (round 2's behaviour)."""
+    from pseudo_speaker_vae_amd import _ffi, latent_classifier as LC
     from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
     torch.manual_seed(0)
     clf = LatentClassifier(64, 3, num_layers=2, hidden_dim=32).to(DEV)
     z = torch.randn(40, 64, device=DEV)
-    y = torch.randint(0, 3, (40,), device=DEV)
-    loss, hits = clf.cross_entropy_step(z, y)
-    assert torch.isfinite(loss)
-    y[7] = -1
-    with pytest.raises(_ffi.PsvaeError, match="label"):
-        clf.cross_entropy_step(z, y)
-    y[7] = 3
-    with pytest.raises(_ffi.PsvaeError, match="label"):
-        clf.cross_entropy_step(z, y)
+    good = torch.randint(0, 3, (40,), device=DEV)
+    bad = good.clone()
+    bad[7] = -1
+    saved = LC.label_watch
+    try:
+        LC.label_watch = w = LC.LabelWatch()
+        w.mode, w.every = "1", 4
+        with pytest.raises(_ffi.PsvaeError, match="label out of range"):      # first batch of a run: checked at once
+            clf.cross_entropy_step(z, bad)
+        LC.label_watch = w = LC.LabelWatch()
+        w.mode, w.every = "1", 4
+        loss, hits = clf.cross_entropy_step(z, good)                            # call 1
+        assert torch.isfinite(loss)
+        loss_bad, _ = clf.cross_entropy_step(z, bad)                            # call 2: no sync, no raise -- but poisoned
+        assert torch.isnan(loss_bad)
+        clf.cross_entropy_step(z, good)                                         # call 3
+        with pytest.raises(_ffi.PsvaeError, match="label outside"):           # call 4: the poll finds the sticky flag
+            clf.cross_entropy_step(z, good)
+        for _ in range(4):                                                      # the flag was cleared: clean steps pass
+            clf.cross_entropy_step(z, good)
+        bad[7] = 3
+        clf.cross_entropy_step(z, good); clf.cross_entropy_step(z, good); clf.cross_entropy_step(z, good)
+        with pytest.raises(_ffi.PsvaeError, match=r"label out of range \[0, 3\): \[3\]"):  # polled on the bad batch itself
+            clf.cross_entropy_step(z, bad)
+        LC.label_watch = w = LC.LabelWatch()
+        w.mode = "sync"
+        clf.cross_entropy_step(z, good)
+        with pytest.raises(_ffi.PsvaeError, match="label out of range"):
+            clf.cross_entropy_step(z, bad)
+    finally:
+        LC.label_watch = saved
 
 
 @pytest.mark.parametrize("cos", [False, True])
