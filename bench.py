@@ -504,6 +504,30 @@ def run_rank(args) -> int:
         plan = eng.tune(x)                       # the committed plan for this GPU model and shape, else heuristics
     mode = args.mode
     allreduce = "none"
+    calibrated = None
+    if mode == "auto" and rk.pg is None and not args.with_adam:
+        # One GPU: the step can be issued as ONE C call that enqueues its launches on the stream ("eager") or replayed
+        # as a captured HIP graph.  Both run the same kernels; a graph replay carries a fixed bubble of a few us per
+        # launch of the graph, the eager form needs a host that stays ahead of the GPU.  Measure both for a moment
+        # (untimed, before the warm-up steps) and take the faster one; config.launch says which, config.calibration
+        # holds both figures.
+        eng.capture(x)
+        def _time(fn, ms=120.0):
+            torch.cuda.synchronize(dev)
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0, n = time.perf_counter(), 0
+            while (time.perf_counter() - t0) * 1e3 < ms:
+                for _ in range(100):
+                    fn()
+                n += 100
+                torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n * 1e6
+        t_graph = _time(eng.replay)
+        t_eager = _time(lambda: eng.forward_backward(x))
+        calibrated = {"graph_us": round(t_graph, 2), "eager_us": round(t_eager, 2)}
+        mode = "eager" if t_eager < t_graph else "graph"
     if mode == "auto":
         mode = "graph"
     if mode == "graph" and rk.pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
@@ -534,7 +558,8 @@ def run_rank(args) -> int:
             if rk.pg is not None:
                 mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
                 allreduce = "one ncclAvg over the flat gradient buffer after the graph"
-            eng.capture(x, with_adam=args.with_adam and rk.pg is None)
+            if eng._graph is None or args.with_adam:
+                eng.capture(x, with_adam=args.with_adam and rk.pg is None)
 
         adam_in_graph = args.with_adam and rk.pg is None
 
@@ -575,9 +600,11 @@ def run_rank(args) -> int:
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
                                    f"batch={B}/GPU, global_batch={B * world}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
-                       "launch": mode, "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
+                       "launch": {"eager": "stream (one C call enqueues the step's launches)",
+                                  "graph": "graph (captured HIP graph, one replay per step)"}.get(mode, mode),
+                       "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
                        "launch_plan": plan, "launches_per_step": eng.launches_per_step(),
-                       "prewarm_ms": args.prewarm_ms},
+                       "prewarm_ms": args.prewarm_ms, "calibration": calibrated},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -17,6 +17,13 @@ namespace psvae {
 
 static inline bool al16h(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// explicit address-space-1 loads: pointers that arrive inside a by-value struct otherwise compile to FLAT loads, which
+// return out of order and force every wait to zero (gemm_f32.hip has the long version of this note)
+#define PSVAE_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 gld4(const float* p) {
+    return *reinterpret_cast<const PSVAE_GLOBAL f32x4*>(reinterpret_cast<uintptr_t>(p));
+}
+
 template <int MAXC>  // Z <= 16 * MAXC
 __global__ __launch_bounds__(256) void bottleneck_fwd_kernel(const BnFwdArgs a) {
     constexpr int ZS = 16 * MAXC + 4;  // LDS row stride of the z tile
@@ -25,12 +32,19 @@ __global__ __launch_bounds__(256) void bottleneck_fwd_kernel(const BnFwdArgs a) 
     __shared__ __attribute__((aligned(16))) float os[16 * OS];
     __shared__ float sh4[4];
     const int B = a.B, Z = a.Z, N = a.N;
-    uint64_t seed = a.seed, offset = a.offset;
-    if (a.rng) { seed = a.rng[0]; offset = a.rng[1]; }
     const int tiles_n = (N + 127) / 128;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int m0 = tm * 16, n0 = tn * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    // Every global read of this kernel is issued up front and consumed later (loads return in order: the kernel then
+    // pays ONE memory round trip, not one per slab / per output row -- the launch computes almost nothing, its length
+    // is its dependent round trips: 8.9 -> see DESIGN 3.2).  The Philox state is read by a vector load for the same reason.
+    uint64_t seed = a.seed, offset = a.offset;
+    unsigned long long rng_s = 0, rng_o = 0;
+    if (a.rng) {
+        rng_s = *reinterpret_cast<const PSVAE_GLOBAL unsigned long long*>(reinterpret_cast<uintptr_t>(a.rng));
+        rng_o = *reinterpret_cast<const PSVAE_GLOBAL unsigned long long*>(reinterpret_cast<uintptr_t>(a.rng + 1));
+    }
     // ---- 0. this wave's weight fragments: issued first, they land while z is being made ----
     const int nc = Z >> 4;
     f32x4 wf[MAXC][2];
@@ -40,8 +54,25 @@ __global__ __launch_bounds__(256) void bottleneck_fwd_kernel(const BnFwdArgs a) 
         for (int b = 0; b < 2; ++b) {
             int n = n0 + 32 * wave + 16 * b + r;
             n = n < N ? n : N - 1;  // clamped columns are never stored
-            wf[c][b] = (c < nc) ? *reinterpret_cast<const f32x4*>(a.W + (size_t)n * Z + 16 * c + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (k chunks past Z: an unconditional load from a clamped address -- a branch around the load would put a
+            //  wait behind it -- and the MFMA loop below skips them)
+            wf[c][b] = gld4(a.W + (size_t)n * Z + 16 * (c < nc ? c : nc - 1) + 4 * q);
         }
+    // (the output pass's bias and table rows: requested now too)
+    f32x4 ob[2], og[2], oa[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + 256 * it, row = i >> 5, col = n0 + 4 * (i & 31);
+        const bool live = m0 + row < B && col < N;
+        ob[it] = live ? gld4(a.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};  // N % 4 == 0
+        og[it] = oa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.ctab && live) {
+            const int g = a.gender[m0 + row], ag = a.age[m0 + row];
+            if (g >= 0 && g < 3) og[it] = gld4(a.ctab + (size_t)g * N + col);
+            if (ag >= 0 && ag < 3) oa[it] = gld4(a.ctab + (size_t)(3 + ag) * N + col);
+        }
+    }
+    if (a.rng) { seed = rng_s; offset = rng_o; }
     // ---- 1. the 16 x Z slice of mu, logvar, z (float4 = one Philox block), KL terms ----
     float kl = 0.f;
     const int zq = Z >> 2;  // float4 per row
@@ -52,7 +83,25 @@ __global__ __launch_bounds__(256) void bottleneck_fwd_kernel(const BnFwdArgs a) 
         if (m0 + row < B) {
             const int64_t e = (int64_t)(m0 + row) * Z + col;
             f32x4 m, l;
-            if (a.S > 0) {
+            if (a.S == 8) {  // H / 64 column tiles of the producing launch: all 16 slab reads in flight at once
+                f32x4 pm[8], pl[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    pm[s] = gld4(a.slab_m + s * slab_stride + e);
+                    pl[s] = gld4(a.slab_s + s * slab_stride + e);
+                }
+                m = gld4(a.b3m + col);
+                l = gld4(a.b3s + col);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {  // the same fixed order as the general loop below: bitwise reproducible
+                    m += pm[s];
+                    l += pl[s];
+                }
+                if (tn == 0) {
+                    *reinterpret_cast<f32x4*>(a.mu + e) = m;
+                    *reinterpret_cast<f32x4*>(a.lv + e) = l;
+                }
+            } else if (a.S > 0) {
                 m = *reinterpret_cast<const f32x4*>(a.b3m + col);
                 l = *reinterpret_cast<const f32x4*>(a.b3s + col);
                 for (int s = 0; s < a.S; ++s) {  // fixed order: bitwise reproducible
@@ -100,16 +149,17 @@ __global__ __launch_bounds__(256) void bottleneck_fwd_kernel(const BnFwdArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) os[(4 * q + j) * OS + 32 * wave + 16 * b + r] = acc[b][j];
     __syncthreads();
-    for (int i = tid; i < 16 * 32; i += 256) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + 256 * it;
         const int row = i >> 5, c4 = i & 31;
         const int col = n0 + 4 * c4;
         if (m0 + row >= B || col >= N) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(os + row * OS + 4 * c4);
-        v += *reinterpret_cast<const f32x4*>(a.bias + col);  // N % 4 == 0
-        if (a.ctab) {
-            const int g = a.gender[m0 + row], ag = a.age[m0 + row];
-            if (g >= 0 && g < 3) v += *reinterpret_cast<const f32x4*>(a.ctab + (size_t)g * N + col);
-            if (ag >= 0 && ag < 3) v += *reinterpret_cast<const f32x4*>(a.ctab + (size_t)(3 + ag) * N + col);
+        v += ob[it];
+        if (a.ctab) {  // (same order of additions as before: bias, gender row, age row)
+            v += og[it];
+            v += oa[it];
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
@@ -173,12 +223,23 @@ __global__ __launch_bounds__(256) void bottleneck_bwd_kernel(const BnBwdArgs a) 
         for (int b = 0; b < 2; ++b) {
             int n = n0 + 32 * wave + 16 * b + r;
             n = n < N ? n : N - 1;
-            const size_t o = (size_t)n * Z + 16 * c + 4 * q;
-            wf[0][c][b] = (c < nc) ? *reinterpret_cast<const f32x4*>(a.W3mT + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wf[1][c][b] = (c < nc) ? *reinterpret_cast<const f32x4*>(a.W3sT + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const size_t o = (size_t)n * Z + 16 * (c < nc ? c : nc - 1) + 4 * q;  // (clamped, as in the forward kernel)
+            wf[0][c][b] = gld4(a.W3mT + o);
+            wf[1][c][b] = gld4(a.W3sT + o);
         }
+    // (the output pass's ReLU masks do not depend on anything computed here: requested now, consumed at the end -- every
+    //  global read of this kernel is in flight before the first is used, see the forward kernel)
+    f32x4 hmask[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + 256 * it;
+        const int e = i >> 9, row = (i >> 5) & 15, col = n0 + 4 * (i & 31);
+        hmask[it] = (m0 + row < B && col < N) ? gld4((e ? a.h2s : a.h2m) + (size_t)(m0 + row) * N + col)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // ---- 1. g_z -> g_mu, g_logvar for the 16 x Z slice ----
-    const float kb = (a.go ? *a.go : 1.0f) * a.beta / (float)B;
+    const float go_v = a.go ? *reinterpret_cast<const PSVAE_GLOBAL float*>(reinterpret_cast<uintptr_t>(a.go)) : 1.0f;
+    const float kb = go_v * a.beta / (float)B;
     const int zq = Z >> 2;
     const size_t slab_stride = (size_t)B * Z;
     for (int i = tid; i < 16 * zq; i += 256) {
@@ -186,11 +247,21 @@ __global__ __launch_bounds__(256) void bottleneck_bwd_kernel(const BnBwdArgs a) 
         f32x4 gm = {0.f, 0.f, 0.f, 0.f}, gl = {0.f, 0.f, 0.f, 0.f};
         if (m0 + row < B) {
             const int64_t e = (int64_t)(m0 + row) * Z + col;
-            f32x4 gz = *reinterpret_cast<const f32x4*>(a.slab_gz + e);
-            for (int s = 1; s < a.S; ++s) gz += *reinterpret_cast<const f32x4*>(a.slab_gz + s * slab_stride + e);
-            const f32x4 m = *reinterpret_cast<const f32x4*>(a.mu + e);
-            const f32x4 l = *reinterpret_cast<const f32x4*>(a.lv + e);
-            const f32x4 ep = *reinterpret_cast<const f32x4*>(a.eps + e);
+            f32x4 gz;
+            if (a.S == 8) {  // all eight slab reads in flight at once; summed in the general loop's order
+                f32x4 pg[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) pg[s] = gld4(a.slab_gz + s * slab_stride + e);
+                gz = pg[0];
+#pragma unroll
+                for (int s = 1; s < 8; ++s) gz += pg[s];
+            } else {
+                gz = *reinterpret_cast<const f32x4*>(a.slab_gz + e);
+                for (int s = 1; s < a.S; ++s) gz += *reinterpret_cast<const f32x4*>(a.slab_gz + s * slab_stride + e);
+            }
+            const f32x4 m = gld4(a.mu + e);
+            const f32x4 l = gld4(a.lv + e);
+            const f32x4 ep = gld4(a.eps + e);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 gm[t] = gz[t] + kb * m[t];
@@ -233,13 +304,15 @@ __global__ __launch_bounds__(256) void bottleneck_bwd_kernel(const BnBwdArgs a) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) os[e][(4 * q + j) * OS + 32 * wave + 16 * b + r] = acc[e][b][j];
     __syncthreads();
-    for (int i = tid; i < 2 * 16 * 32; i += 256) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + 256 * it;
         const int e = i >> 9, row = (i >> 5) & 15, c4 = i & 31;
         const int col = n0 + 4 * c4;
         if (m0 + row >= B || col >= N) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(os[e] + row * OS + 4 * c4);
         const size_t o = (size_t)(m0 + row) * N + col;
-        const f32x4 hm = *reinterpret_cast<const f32x4*>((e ? a.h2s : a.h2m) + o);
+        const f32x4 hm = hmask[it];
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = hm[t] > 0.f ? v[t] : 0.f;
         *reinterpret_cast<f32x4*>((e ? a.dh2s : a.dh2m) + o) = v;

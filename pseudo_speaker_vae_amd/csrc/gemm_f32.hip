@@ -128,6 +128,16 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
     const bool fastB = vecB && (!BKM || bn + 16 * TN <= N);
     const bool vec = fastA && fastB;
 
+#ifdef PSVAE_STAMP  // diagnostic build only (tools/build_variant.sh stamp -DPSVAE_STAMP; tools/stamp_f32.py): wave 0 of every
+                    // workgroup prints its phase lengths in shader cycles and its entry / exit on the 100 MHz clock
+    unsigned long long st_[8];
+    int nst_ = 0;
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#define STAMP() do { if (nst_ < 8) st_[nst_++] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP();
+#else
+#define STAMP() do {} while (0)
+#endif
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -166,6 +176,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
         }
     };
 
+    STAMP();  // 1: descriptor decoded, addresses ready
     int c = cbeg;
     if (vec) {
         // fast region: whole groups of D chunks that are interior in k.  Software pipeline over a ring of D
@@ -219,6 +230,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             if (c + s < cend) mma(s);
     }
 
+    STAMP();  // 2: k loop done (all MFMAs issued)
     // second stage (see below): its weight fragments are requested NOW, so that they land while the k-slices are being
     // reduced through LDS (the main loop's fragment ring is dead from here on: the registers are free)
     f32x4 b4[S2 ? 4 : 1][4];
@@ -252,6 +264,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
         }
     }
     __syncthreads();
+    STAMP();  // 3: every wave's partial tile is in LDS
     const int epi = d.epi;
     float* __restrict__ C = d.C + (size_t)ksg * M * d.ldc;  // ksplit > 1: this slice's slab
     const float* __restrict__ aux = d.aux;
@@ -280,14 +293,21 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
     // NOT unrolled: this code runs once per workgroup, straight from a cold instruction cache (consecutive launches of
     // a step are different kernels) -- four copies of the row body cost more in instruction fetch than the loop
     // overhead saves (config 6: 72 -> 46 KB of code; step 153.9 -> 150.8 us untuned, 146.8 -> 144.9 us tuned, same box)
-#pragma unroll 1
+#ifndef PSVAE_ROW_UNROLL
+#define PSVAE_ROW_UNROLL 1
+#endif
+#pragma unroll PSVAE_ROW_UNROLL
     for (int rr = 0; rr < BM; rr += RSTEP) {
         const int lr = rr + r0;
         const int row = m0 + lr;
         if (lr >= BM || row >= M || col >= N) continue;
+#ifdef PSVAE_DIAG_NOLDSRD  // (diagnostic builds only: wrong results, for timing what a phase costs)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#else
         f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * SC + 4 * c4);
 #pragma unroll
         for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * (BM * SC) + lr * SC + 4 * c4);
+#endif
         const size_t o = (size_t)row * ldc + col;
         const bool full = vecC && (col + 3 < N);
         if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) {
@@ -367,6 +387,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (epi == EPI_MASK) ? (w[e] > 0.f ? v[e] : 0.f) : v[e] + w[e];
         }
+#ifdef PSVAE_DIAG_NOSTORE
+        if (v[0] == 123.456f) stg<f32x4>(C + o, v);
+#else
         if (full) {
             stg<f32x4>(C + o, v);
         } else {
@@ -374,8 +397,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
             for (int e = 0; e < 4; ++e)
                 if (col + e < N) stg<float>(C + o + e, v[e]);
         }
+#endif
         if (S2) *reinterpret_cast<f32x4*>(smem + lr * SC + 4 * c4) = v;  // the finished tile stays in LDS for stage 2
     }
+    STAMP();  // 4: row loop done (stores issued)
     if (S2) {
         // ---- second stage: slab2[tn][row][:] = T[row][0..BN) * B2[n0.., :] (see GemmDesc::B2).  Wave w owns tile rows
         // 16w..16w+15; A fragments come from LDS (4 consecutive k per lane, as the "KC" operand of the main loop), B
@@ -462,6 +487,16 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, int
         for (int k2 = 1; k2 < KS; ++k2) s += csum_s[k2 * BM + tid];
         if (m0 + tid < M) stg<float>(d.colsum + (size_t)ksg * M + m0 + tid, s);
     }
+#ifdef PSVAE_STAMP
+    __builtin_amdgcn_s_waitcnt(0);  // stores of this wave done (vmcnt 0)
+    STAMP();  // 5: stage 2 / loss tail / own stores drained
+    if (tid == 0) {
+        const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();
+        printf("S kind=%d M=%d N=%d K=%d cfg=%d epi=%d s2=%d wg=%d rt0=%llu rt1=%llu d=%llu,%llu,%llu,%llu,%llu\n", d.kind, M, N, K,
+               d.cfg, d.epi, (int)(S2 && d.B2 != nullptr), (int)blockIdx.x, rt0_, rt1_, st_[1] - st_[0], st_[2] - st_[1],
+               st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4]);
+    }
+#endif
 }
 
 // ---- configurations -------------------------------------------------------------------------------
