@@ -496,6 +496,21 @@ def run_rank(args) -> int:
     if args.cond:
         eng.set_labels(torch.randint(0, 3, (B,), generator=g), torch.randint(0, 3, (B,), generator=g))
 
+    gather = None
+    if args.gather:
+        # batch assembly inside the timed step (ps_vae/data/cv.py:58-76 loads one file per sample; here the dataset is one
+        # [N, D] table in HBM and a batch is an index gather, pseudo_speaker_vae_amd/data.py): a CommonVoice-sized table
+        # (674,068 rows, plots/dataset_info_train.json) of synthetic rows, a shuffled epoch permutation on the device,
+        # every step gathers ITS rows into the step's input buffer with psvae_gather_rows_f32 before the pass runs
+        from pseudo_speaker_vae_amd.data import PackedEmbeddingTable
+        n_rows = args.table_rows
+        tab = PackedEmbeddingTable(torch.randn(n_rows, D, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank)), device=dev)
+        perm = torch.randperm(n_rows, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + rank))
+        nb = n_rows // B
+        def gather(i, out):
+            o = (i % nb) * B
+            tab.batch(perm[o:o + B], out=out)
+
     if args.plan:
         plan = eng.tune(x, plan=args.plan)       # an explicit plan (text form printed as config.launch_plan)
     elif args.tune:
@@ -524,8 +539,12 @@ def run_rank(args) -> int:
                 n += 100
                 torch.cuda.synchronize(dev)
             return (time.perf_counter() - t0) / n * 1e6
-        t_graph = _time(eng.replay)
-        t_eager = _time(lambda: eng.forward_backward(x))
+        if gather is not None:
+            t_graph = _time(lambda: (gather(0, eng.static_x), eng.replay()))
+            t_eager = _time(lambda: (gather(0, x), eng.forward_backward(x)))
+        else:
+            t_graph = _time(eng.replay)
+            t_eager = _time(lambda: eng.forward_backward(x))
         calibrated = {"graph_us": round(t_graph, 2), "eager_us": round(t_eager, 2)}
         mode = "eager" if t_eager < t_graph else "graph"
     if mode == "auto":
@@ -564,6 +583,8 @@ def run_rank(args) -> int:
         adam_in_graph = args.with_adam and rk.pg is None
 
         def step(i):
+            if gather is not None:
+                gather(i, eng.static_x)
             eng.replay()
             if args.with_adam and not adam_in_graph:
                 eng.optimizer_step()
@@ -572,6 +593,8 @@ def run_rank(args) -> int:
             allreduce = "2 buckets (decoder first), async under the encoder backward"
 
         def step(i):
+            if gather is not None:
+                gather(i, x)
             eng.forward_backward(x)
             if args.with_adam:
                 eng.optimizer_step()
@@ -596,6 +619,7 @@ def run_rank(args) -> int:
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{config_label(D, Z, B, args.dtype, args.cond)}: "
                                    f"{'conditional (one-hot gender+age) ' if args.cond else ''}"
+                                   f"{'batch gather from a ' + str(args.table_rows) + '-row packed table in HBM + ' if args.gather else ''}"
                                    f"VAE fwd+ELBO+bwd{'+Adam' if args.with_adam else ''}"
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
                                    f"batch={B}/GPU, global_batch={B * world}, "
@@ -603,6 +627,9 @@ def run_rank(args) -> int:
                        "launch": {"eager": "stream (one C call enqueues the step's launches)",
                                   "graph": "graph (captured HIP graph, one replay per step)"}.get(mode, mode),
                        "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
+                       "batch_source": ("each step's rows gathered on the device from a shuffled packed table "
+                                        "(psvae_gather_rows_f32, inside the timed step)") if args.gather else
+                                       "one static batch resident in HBM (batch assembly is outside the timed step; --gather times it)",
                        "launch_plan": plan, "launches_per_step": eng.launches_per_step(),
                        "prewarm_ms": args.prewarm_ms, "calibration": calibrated},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
@@ -638,6 +665,10 @@ def parse_args(argv=None):
                     help="train = cfg2 (headline); decode = cfg5 decode-only sampling; langevin = cfg5 conditional "
                          "sampling (Langevin chain + decode); --samples rows in total; api-step = the train shape "
                          "through PseudoSpeakerVAE.training_step + loss.backward() (the drop-in API path)")
+    ap.add_argument("--gather", action="store_true",
+                    help="train workload: assemble each step's batch from a packed embedding table in HBM inside the "
+                         "timed step (a CommonVoice-sized table of synthetic rows, shuffled epoch order)")
+    ap.add_argument("--table-rows", type=int, default=674068, help="--gather: rows of the packed table")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed: run the step for this long before the W warm-up steps (clocks / caches of a run in "
                          "progress); 0 = off")
