@@ -298,7 +298,12 @@ def bench_decode(args, rk: Rank):
     nbytes = _ffi.lib().psvae_decode_bf16_scratch_bytes(n, D, Z) if bf16 else _ffi.lib().psvae_decode_scratch_bytes(n)
     scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
 
+    separate = os.environ.get("PSVAE_DECODE_SEPARATE_DRAW") == "1"  # comparison: draw launch + decode (round 2's form)
+
     def step(i):
+        if not separate:  # z drawn inside the fused decode kernel (psvae_sample_decode_*): one call
+            ops.sample_decode(n, Z, dec, D, 1234 + rank, i * ((n * Z + 3) // 4), bf16=bf16, out=out, scratch=scratch)
+            return
         _ffi.check(_ffi.lib().psvae_philox_normal_f32(z.data_ptr(), n * Z, 1234 + rank, i * ((n * Z + 3) // 4),
                                                       torch.cuda.current_stream().cuda_stream), "philox")
         if bf16:
@@ -317,7 +322,8 @@ def bench_decode(args, rk: Rank):
             "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"cfg5: decode-only sampling, {n * world} rows per step ({n}/GPU), d_in={D} z={Z}, "
-                                   "Philox z on device + 3-layer decoder"
+                                   + ("Philox z on device (separate launch) + 3-layer decoder" if separate else
+                                      "z drawn from Philox inside the fused 3-layer decode kernel")
                                    + (" (bf16 operands / fp32 accumulate)" if bf16 else ""), "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None, "flop_per_embedding": fpe}}), flush=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSVAE_ABI_VERSION 3
+#define PSVAE_ABI_VERSION 4
 #define PSVAE_HIDDEN 512
 #define PSVAE_NPARAM 18
 #define PSVAE_COND_DIM 6 /* onehot3(gender) || onehot3(age), SURVEY.md section 8a row A9 */
@@ -217,6 +217,18 @@ int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const flo
 int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const float* const* dec6,
                      const float* cond_tab /* nullable [6,512] */, const int32_t* gender,
                      const int32_t* age, float* x_hat, void* scratch, uint32_t flags, void* stream);
+/* unconditional_synthesis in ONE call (inference.py:10-27: z = torch.randn((num_samples, dim)); x_hat = decode(z)):
+ * z[N,Z] ~ N(0, I) from the Philox stream (seed, offset) -- element e of the flat array is normal (e % 4) of block
+ * offset + e / 4, exactly what psvae_philox_normal_f32(z, N * Z, seed, offset) writes -- then x_hat = decoder(z).  On the
+ * fused decode's shapes (see psvae_last_decode_launches) z is drawn INSIDE the decode kernel: no draw launch, no round
+ * trip of z through memory; z_out is nullable there and receives the fp32 z when given.  Other shapes draw into z_out
+ * first (PSVAE_ERR_NULL without it) and call psvae_decode_*.  Same scratch as psvae_decode_f32 / psvae_decode_bf16. */
+int psvae_sample_decode_f32(int64_t N, int64_t D, int64_t Z, uint64_t seed, uint64_t offset, const float* const* dec6,
+                            float* z_out /* nullable on fused shapes */, float* x_hat, void* scratch, uint32_t flags,
+                            void* stream);
+int psvae_sample_decode_bf16(int64_t N, int64_t D, int64_t Z, uint64_t seed, uint64_t offset, const float* const* dec6,
+                             float* z_out /* nullable on fused shapes */, float* x_hat, void* scratch, uint32_t flags,
+                             void* stream);
 /* kernel launches the calling thread's most recent psvae_decode_f32 issued: the fused decode (all three
  * layers in one kernel; N >= 16384, no conditional table, Z in {32,64,128}, D in {128,256,512}) issues 4 (three weight
  * packs + the kernel) plus the normalisation launches, the per-layer path 3 per 65,536-row chunk */

@@ -21,7 +21,7 @@ COND_DIM = 6
 NORMALIZE_DECODER = 1
 COS_LOSS = 2
 PHASE_DECODER, PHASE_ENCODER, PHASE_ALL = 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/psvae.h declares (tests check the .so exports each of them)
 SYMBOLS = (
@@ -32,7 +32,7 @@ SYMBOLS = (
     "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
-    "psvae_last_decode_launches", "psvae_last_step_launches_bf16",
+    "psvae_last_decode_launches", "psvae_last_step_launches_bf16", "psvae_sample_decode_f32", "psvae_sample_decode_bf16",
 )
 
 
@@ -158,6 +158,9 @@ def lib() -> C.CDLL:
     L.psvae_backward_bf16.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, f32, vp,
                                       C.POINTER(Grads), vp, vp, u32, vp]
     L.psvae_backward_bf16.restype = C.c_int
+    for fn in (L.psvae_sample_decode_f32, L.psvae_sample_decode_bf16):
+        fn.argtypes = [i64, i64, i64, u64, u64, C.POINTER(vp), vp, vp, vp, u32, vp]
+        fn.restype = C.c_int
     L.psvae_gather_rows_f32.argtypes = [vp, i64, i64, vp, i64, vp, vp]
     L.psvae_gather_rows_f32.restype = C.c_int
     f64 = C.c_double

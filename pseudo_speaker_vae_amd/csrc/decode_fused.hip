@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "psvae_common.h"
+#include "psvae_device.h"
 
 namespace psvae {
 
@@ -39,7 +40,11 @@ __global__ __launch_bounds__(256) void pack_decode_weights_kernel(const float* _
 constexpr int DF_MAXP = 8;  // pieces per thread of the largest chunk (MBO = 32: 32 KB)
 
 struct DecodeFusedArgs {
-    const float* z;       // [N, Z]
+    const float* z;       // [N, Z]; NULL = draw z ~ N(0, I) here: element e of the flat [N, Z] array is normal (e % 4) of
+                          // Philox block offset + e / 4 under `seed` -- exactly what psvae_philox_normal_f32 would have
+                          // written (inference.py:22-23: torch.randn((num_samples, dim))), without the launch and the round trip
+    float* z_out;         // nullable: receives the z that was read or drawn
+    unsigned long long seed, offset;
     float* x_hat;         // [N, D]
     const float* wp;      // packed weights: layer 0 | layer 1 | layer 2
     const float* bias0;   // [512]
@@ -109,8 +114,20 @@ __global__ __launch_bounds__(256, 1) void decode_fused_kernel(const DecodeFusedA
         return row < a.N ? row : a.N - 1;
     };
     f32x4 znext[ZB];  // the next tile's latent rows, requested a layer ahead
+    const bool draw = a.z == nullptr;
     auto zfetch = [&](long tile) {
-        const float* zp = a.z + zrow(tile) * a.Z + 4 * q;
+        const long zr = zrow(tile);
+        if (draw) {  // ZB Philox blocks per lane and tile (~1 % of the tile's cycles, issued ahead of layer 2's MFMAs)
+            const long row = tile * 64 + wave * 16 + r;
+#pragma unroll
+            for (int mb = 0; mb < ZB; ++mb) {
+                const unsigned long long e = (unsigned long long)zr * a.Z + 16 * mb + 4 * q;
+                znext[mb] = philox_normal4_hw(a.offset + (e >> 2), a.seed);
+                if (a.z_out && row < a.N) *reinterpret_cast<f32x4*>(a.z_out + e) = znext[mb];
+            }
+            return;
+        }
+        const float* zp = a.z + zr * a.Z + 4 * q;
 #pragma unroll
         for (int mb = 0; mb < ZB; ++mb) znext[mb] = *reinterpret_cast<const f32x4*>(zp + 16 * mb);
     };
@@ -231,7 +248,7 @@ static hipError_t launch_decode_fused_t(const DecodeFusedArgs& a, hipStream_t s)
 
 // pack the three weight matrices into `wp` (decode_fused_pack_floats floats) and run the fused kernel
 hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat, float* wp,
-                               hipStream_t s) {
+                               hipStream_t s, unsigned long long seed, unsigned long long offset, float* z_out) {
     float* wp0 = wp;
     float* wp1 = wp0 + (size_t)H * Z;
     float* wp2 = wp1 + (size_t)H * H;
@@ -240,7 +257,7 @@ hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const fl
     hipLaunchKernelGGL(pack_decode_weights_kernel, dim3(256), dim3(256), 0, s, dec6[4], wp2, D, H);
     DecodeFusedArgs a{};
     a.z = z; a.x_hat = x_hat; a.wp = wp; a.bias0 = dec6[1]; a.bias1 = dec6[3]; a.bias2 = dec6[5];
-    a.N = N; a.Z = Z; a.D = D;
+    a.N = N; a.Z = Z; a.D = D; a.seed = seed; a.offset = offset; a.z_out = z ? nullptr : z_out;
 #define PSVAE_DF(ZB, DB) if (Z == 16 * ZB && D == 16 * DB) return launch_decode_fused_t<ZB, DB>(a, s)
     PSVAE_DF(4, 16); PSVAE_DF(8, 32); PSVAE_DF(2, 16); PSVAE_DF(4, 8); PSVAE_DF(4, 32); PSVAE_DF(8, 16);
     PSVAE_DF(2, 8); PSVAE_DF(2, 32); PSVAE_DF(8, 8);
@@ -296,7 +313,10 @@ __device__ unsigned long long g_dstamp[8];
 #endif
 
 struct DecodeFusedBfArgs {
-    const float* z;            // [N, Z] fp32 (rounded to bf16 on load, as the per-layer path's cast does)
+    const float* z;            // [N, Z] fp32 (rounded to bf16 on load, as the per-layer path's cast does); NULL = drawn
+                               // in the kernel (see DecodeFusedArgs::z)
+    float* z_out;              // nullable (drawing kernels): receives the fp32 z
+    unsigned long long seed, offset;
     float* x_hat;              // [N, D]
     const unsigned short* wp;  // packed bf16 weights: layer 0 | layer 1 | layer 2
     const float* bias0;
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(256) void pack_decode_weights_bf16w_kernel(const fl
     }
 }
 
-template <int ZK, int DBW>  // Z = 32 ZK, D = 64 DBW, hidden = 512
+template <int ZK, int DBW, bool DRAW = false>  // Z = 32 ZK, D = 64 DBW, hidden = 512; DRAW: z comes from Philox, not memory
 __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFusedBfArgs a) {
     constexpr int HK = H / 32;                       // 16 k steps of a hidden input
     constexpr int S = ZK + HK + HK;                  // k steps of the whole weight stream per tile
@@ -380,7 +400,31 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
             }
         }
     };
-    zfetch(blockIdx.x);
+    // DRAW: the same rows' z as Philox normals, one block of four per 16-byte piece -- 4 ZK pieces per lane and tile.  The
+    // first tile's are made here; the next tile's are made PIECE BY PIECE inside layer 2's k loop (piece p between the
+    // MFMAs of k step p), where the vector ALU is otherwise idle: the separate draw launch (94 us per 1 M rows) and the
+    // 256 MB round trip of z disappear, the tile pays nothing visible.
+    auto zpiece = [&](long tile, auto Pc) {
+        constexpr int p = decltype(Pc)::value;
+        constexpr int g = p / (2 * ZK), kbz = (p % (2 * ZK)) / 2, h = p % 2;
+        const long row = tile * 128 + 32 * wave + 16 * g + r;
+        const unsigned long long e = (unsigned long long)(row < a.N ? row : a.N - 1) * a.Z + 32 * kbz + 16 * h + 4 * q;
+        zn[g][kbz][h] = philox_normal4_hw(a.offset + (e >> 2), a.seed);
+        if (a.z_out && row < a.N) *reinterpret_cast<f32x4*>(a.z_out + e) = zn[g][kbz][h];
+    };
+    if constexpr (DRAW) {
+        zpiece(blockIdx.x, std::integral_constant<int, 0>{});
+        if constexpr (ZK >= 1) { zpiece(blockIdx.x, std::integral_constant<int, 1>{}); zpiece(blockIdx.x, std::integral_constant<int, 2>{}); zpiece(blockIdx.x, std::integral_constant<int, 3>{}); }
+        if constexpr (ZK >= 2) { zpiece(blockIdx.x, std::integral_constant<int, 4>{}); zpiece(blockIdx.x, std::integral_constant<int, 5>{}); zpiece(blockIdx.x, std::integral_constant<int, 6>{}); zpiece(blockIdx.x, std::integral_constant<int, 7>{}); }
+        if constexpr (ZK >= 4) {
+            zpiece(blockIdx.x, std::integral_constant<int, 8>{}); zpiece(blockIdx.x, std::integral_constant<int, 9>{});
+            zpiece(blockIdx.x, std::integral_constant<int, 10>{}); zpiece(blockIdx.x, std::integral_constant<int, 11>{});
+            zpiece(blockIdx.x, std::integral_constant<int, 12>{}); zpiece(blockIdx.x, std::integral_constant<int, 13>{});
+            zpiece(blockIdx.x, std::integral_constant<int, 14>{}); zpiece(blockIdx.x, std::integral_constant<int, 15>{});
+        }
+    } else {
+        zfetch(blockIdx.x);
+    }
     wfetch(0);
     wfetch(1);
     __syncthreads();  // sbias
@@ -404,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
         f32x4 acc[8][8];  // [block of this wavefront][row group]
         int s = 0;        // k step of the weight stream
         // one layer: KB k steps over MB blocks x 8 row groups; the bias is the first step's C operand
-        auto layer = [&](auto KBc, auto MBc, const float* bias) {
+        auto layer = [&](auto KBc, auto MBc, const float* bias, auto between) {
             constexpr int KB = decltype(KBc)::value, MB = decltype(MBc)::value;
             f32x4 bv[MB];
 #pragma unroll
@@ -419,6 +463,7 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
                 else if (S % NA == 0) wfetch(s + 2 - S);
                 if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                between(kb);  // (vector-ALU work the scheduler may interleave with this step's MFMAs)
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
@@ -446,16 +491,28 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
             __syncthreads();
         };
         RSTAMP(1);
-        layer(std::integral_constant<int, ZK>{}, std::integral_constant<int, 8>{}, sbias);
+        auto nothing = [](int) {};
+        layer(std::integral_constant<int, ZK>{}, std::integral_constant<int, 8>{}, sbias, nothing);
         RSTAMP(2);
         publish();
         RSTAMP(3);
-        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{}, sbias + H);
+        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{}, sbias + H, nothing);
         RSTAMP(4);
         publish();
         RSTAMP(5);
-        zfetch(tile + gridDim.x);
-        layer(std::integral_constant<int, HK>{}, std::integral_constant<int, DBW>{}, sbias + 2 * H);
+        if constexpr (DRAW) {
+            const long nxt = tile + gridDim.x;
+            layer(std::integral_constant<int, HK>{}, std::integral_constant<int, DBW>{}, sbias + 2 * H, [&](int kb) {
+                // (kb is a constant after unrolling; 4 ZK <= 16 pieces over the 16 k steps)
+#define PSVAE_ZP(P) if (kb == P && P < 4 * ZK) zpiece(nxt, std::integral_constant<int, (P < 4 * ZK ? P : 0)>{})
+                PSVAE_ZP(0); PSVAE_ZP(1); PSVAE_ZP(2); PSVAE_ZP(3); PSVAE_ZP(4); PSVAE_ZP(5); PSVAE_ZP(6); PSVAE_ZP(7);
+                PSVAE_ZP(8); PSVAE_ZP(9); PSVAE_ZP(10); PSVAE_ZP(11); PSVAE_ZP(12); PSVAE_ZP(13); PSVAE_ZP(14); PSVAE_ZP(15);
+#undef PSVAE_ZP
+            });
+        } else {
+            zfetch(tile + gridDim.x);
+            layer(std::integral_constant<int, HK>{}, std::integral_constant<int, DBW>{}, sbias + 2 * H, nothing);
+        }
         RSTAMP(6);
         if (S % NA != 0) {  // (their latency runs under the stores, the barrier and the latent rows' write)
             wfetch(0);
@@ -507,16 +564,16 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
 #endif
 }
 
-template <int ZK, int DBW>
+template <int ZK, int DBW, bool DRAW>
 static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
     constexpr int RPP = DBW == 8 ? 64 : 128, RS = 256 * DBW + 16;
     constexpr size_t lds = (size_t)(RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024) + (size_t)(2 * H + 64 * DBW) * sizeof(float);
     static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
-    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW>), 160 * 1024))
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW, DRAW>), 160 * 1024))
         return attr_err;
     const long ntiles = (a.N + 127) / 128;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW, DRAW>), dim3(grid), dim3(256), lds, s, a);
 #ifdef PSVAE_STAMP
     {
         unsigned long long h[8];
@@ -531,7 +588,8 @@ static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStrea
 }
 
 hipError_t launch_decode_rows_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
-                                   unsigned short* wp, hipStream_t s) {
+                                   unsigned short* wp, hipStream_t s, unsigned long long seed, unsigned long long offset,
+                                   float* z_out) {
     unsigned short* wp0 = wp;
     unsigned short* wp1 = wp0 + (size_t)H * Z;
     unsigned short* wp2 = wp1 + (size_t)H * H;
@@ -540,8 +598,9 @@ hipError_t launch_decode_rows_bf16(int64_t N, int Z, int D, const float* z, cons
     hipLaunchKernelGGL(pack_decode_weights_bf16w_kernel, dim3(256), dim3(256), 0, s, dec6[4], wp2, D, H);
     DecodeFusedBfArgs a{};
     a.z = z; a.x_hat = x_hat; a.wp = wp; a.bias0 = dec6[1]; a.bias1 = dec6[3]; a.bias2 = dec6[5];
-    a.N = N; a.Z = Z; a.D = D;
-#define PSVAE_DRB(ZK, DBW) if (Z == 32 * ZK && D == 64 * DBW) return launch_decode_rows_bf16_t<ZK, DBW>(a, s)
+    a.N = N; a.Z = Z; a.D = D; a.seed = seed; a.offset = offset; a.z_out = z ? nullptr : z_out;
+#define PSVAE_DRB(ZK, DBW) if (Z == 32 * ZK && D == 64 * DBW) \
+        return z ? launch_decode_rows_bf16_t<ZK, DBW, false>(a, s) : launch_decode_rows_bf16_t<ZK, DBW, true>(a, s)
     PSVAE_DRB(2, 4); PSVAE_DRB(1, 4); PSVAE_DRB(4, 4); PSVAE_DRB(2, 2); PSVAE_DRB(1, 2); PSVAE_DRB(4, 2);
     PSVAE_DRB(2, 8); PSVAE_DRB(1, 8); PSVAE_DRB(4, 8);
 #undef PSVAE_DRB
@@ -556,8 +615,9 @@ bool decode_fused_bf16_ok(int64_t N, int Z, int D) {
 
 // pack (cast + permute) the three weight matrices into `wp` ((H Z + H H + D H) bf16) and run the fused kernel
 hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
-                                    unsigned short* wp, hipStream_t s) {
-    return launch_decode_rows_bf16(N, Z, D, z, dec6, x_hat, wp, s);
+                                    unsigned short* wp, hipStream_t s, unsigned long long seed, unsigned long long offset,
+                                    float* z_out) {
+    return launch_decode_rows_bf16(N, Z, D, z, dec6, x_hat, wp, s, seed, offset, z_out);
 }
 
 }  // namespace psvae

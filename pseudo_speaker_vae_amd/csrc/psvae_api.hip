@@ -968,6 +968,40 @@ int psvae_decode_f32(int64_t N, int64_t D, int64_t Z, const float* z, const floa
     return 0;
 }
 
+// unconditional_synthesis in one call (inference.py:10-27): z ~ N(0, I) [N, Z] from the Philox stream (seed, offset) --
+// element e = normal (e % 4) of block offset + e / 4, what psvae_philox_normal_f32 writes -- then x_hat = decoder(z).  On the
+// fused decode's shapes z is drawn INSIDE the decode kernel: no draw launch, no round trip of z through memory (z_out,
+// nullable there, receives it when given); other shapes need z_out as the place to draw into first.
+int psvae_sample_decode_f32(int64_t N, int64_t D, int64_t Z, uint64_t seed, uint64_t offset, const float* const* dec6,
+                            float* z_out, float* x_hat, void* scratch, uint32_t flags, void* stream) {
+    if (N <= 0 || D <= 0 || Z <= 0) return PSVAE_ERR_SHAPE;
+    if (!dec6 || !x_hat || !scratch) return PSVAE_ERR_NULL;
+    for (int i = 0; i < 6; ++i)
+        if (!dec6[i]) return PSVAE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t c = N < DECODE_CHUNK ? N : DECODE_CHUNK;
+    if (decode_fused_ok(N, (int)Z, (int)D) && ((N * Z) & 3) == 0 &&
+        decode_fused_pack_floats((int)Z, (int)D) * sizeof(float) <= 2 * align_up((size_t)c * H * sizeof(float), 256)) {
+        t_decode_launches = 0;
+        float* d1 = reinterpret_cast<float*>(scratch);
+        float* yn = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 2 * align_up((size_t)c * H * sizeof(float), 256));
+        RET_IF(launch_decode_fused(N, (int)Z, (int)D, nullptr, dec6, x_hat, d1, s, seed, offset, z_out));
+        t_decode_launches += 4;
+        if (flags & PSVAE_NORMALIZE_DECODER)
+            for (int64_t r0 = 0; r0 < N; r0 += c) {
+                const int n = (int)((N - r0) < c ? (N - r0) : c);
+                RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+                ++t_decode_launches;
+            }
+        return 0;
+    }
+    if (!z_out) return PSVAE_ERR_NULL;
+    RET_IF(launch_philox_normal(z_out, N * Z, seed, offset, s));
+    const int rc = psvae_decode_f32(N, D, Z, z_out, dec6, nullptr, nullptr, nullptr, x_hat, scratch, flags, stream);
+    ++t_decode_launches;
+    return rc;
+}
+
 int psvae_last_decode_launches(void) { return t_decode_launches; }
 
 int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const float* W1, const float* b1,

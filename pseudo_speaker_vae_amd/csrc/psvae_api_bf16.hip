@@ -549,4 +549,33 @@ int psvae_decode_bf16(int64_t N, int64_t D, int64_t Z, const float* z, const flo
     return 0;
 }
 
+// psvae_sample_decode_f32 with bf16 operands (see there): on the fused decode's shapes z is drawn inside the decode kernel
+int psvae_sample_decode_bf16(int64_t N, int64_t D, int64_t Z, uint64_t seed, uint64_t offset, const float* const* dec6,
+                             float* z_out, float* x_hat, void* scratch, uint32_t flags, void* stream) {
+    if (N <= 0 || D <= 0 || Z <= 0) return PSVAE_ERR_SHAPE;
+    if ((Z & 31) || (D & 3)) return PSVAE_ERR_SHAPE;
+    if (!dec6 || !x_hat || !scratch) return PSVAE_ERR_NULL;
+    for (int i = 0; i < 6; ++i)
+        if (!dec6[i]) return PSVAE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (decode_fused_bf16_ok(N, (int)Z, (int)D)) {
+        const int64_t c = N < DECODE_CHUNK_BF ? N : DECODE_CHUNK_BF;
+        char* base = reinterpret_cast<char*>(scratch);
+        u16* Wb0 = reinterpret_cast<u16*>(base);
+        size_t off = align_up((size_t)(H * Z + H * H + D * H) * 2, 256);
+        off += align_up((size_t)c * Z * 2, 256) + 2 * align_up((size_t)c * H * 2, 256);
+        float* yn = reinterpret_cast<float*>(base + off);
+        RET_IF(launch_decode_fused_bf16(N, (int)Z, (int)D, nullptr, dec6, x_hat, Wb0, s, seed, offset, z_out));
+        if (flags & PSVAE_NORMALIZE_DECODER)
+            for (int64_t r0 = 0; r0 < N; r0 += c) {
+                const int n = (int)((N - r0) < c ? (N - r0) : c);
+                RET_IF(launch_normalize_rows(x_hat + r0 * D, x_hat + r0 * D, yn, n, (int)D, s));
+            }
+        return 0;
+    }
+    if (!z_out) return PSVAE_ERR_NULL;
+    RET_IF(launch_philox_normal(z_out, N * Z, seed, offset, s));
+    return psvae_decode_bf16(N, D, Z, z_out, dec6, x_hat, scratch, flags, stream);
+}
+
 }  // extern "C"

@@ -300,11 +300,15 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 // decode_fused.hip: the three decoder layers in one kernel (hidden activations stay in registers)
 bool decode_fused_ok(int64_t N, int Z, int D);
 size_t decode_fused_pack_floats(int Z, int D);
+// z == NULL: the kernel draws z itself (Philox normals of (seed, offset), the stream psvae_philox_normal_f32 writes) and
+// leaves it in z_out when that is given
 hipError_t launch_decode_fused(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat, float* wp,
-                               hipStream_t s);
+                               hipStream_t s, unsigned long long seed = 0, unsigned long long offset = 0,
+                               float* z_out = nullptr);
 bool decode_fused_bf16_ok(int64_t N, int Z, int D);
 hipError_t launch_decode_fused_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,
-                                    unsigned short* wp, hipStream_t s);
+                                    unsigned short* wp, hipStream_t s, unsigned long long seed = 0,
+                                    unsigned long long offset = 0, float* z_out = nullptr);
 
 // chain_bf16.hip: a 3-layer MLP of the bf16 training pass (one encoder, or the decoder) over 64-row tiles in one launch
 struct ChainArgs {

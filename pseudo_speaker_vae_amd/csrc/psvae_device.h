@@ -36,6 +36,23 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t blk, uint64_t seed) {
     return f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
 }
 
+// The same draw with the hardware transcendentals only (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 -- which take their
+// argument in REVOLUTIONS, so sin(2 pi u) is v_sin_f32(u)): straight-line code, no range-reduction branches, which is what
+// lets the scheduler weave it between MFMAs (the fused decode kernels draw z this way: psvae_sample_decode_*).  Differs from
+// philox_normal4 by the instructions' accuracy, a few 1e-7 of |z| (tests hold it to 2e-6 of the largest |z|).
+__device__ __forceinline__ f32x4 philox_normal4_hw(uint64_t blk, uint64_t seed) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    constexpr float S = 5.9604644775390625e-08f;  // 2^-24
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * S, u1 = ((float)(r[1] >> 8) + 0.5f) * S;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * S, u3 = ((float)(r[3] >> 8) + 0.5f) * S;
+    constexpr float M2LN2 = -1.3862943611198906f;  // -2 ln 2: -2 ln u = M2LN2 * log2 u
+    const float ra = __builtin_amdgcn_sqrtf(M2LN2 * __builtin_amdgcn_logf(u0));
+    const float rb = __builtin_amdgcn_sqrtf(M2LN2 * __builtin_amdgcn_logf(u2));
+    return f32x4{ra * __builtin_amdgcn_cosf(u1), ra * __builtin_amdgcn_sinf(u1), rb * __builtin_amdgcn_cosf(u3),
+                 rb * __builtin_amdgcn_sinf(u3)};
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------

@@ -281,6 +281,30 @@ def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: i
     return xh
 
 
+def sample_decode(N: int, Z: int, dec_params: Sequence[torch.Tensor], D: int, seed: int, offset: int, flags: int = 0,
+                  bf16: bool = False, out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None,
+                  z_out: Optional[torch.Tensor] = None, want_z: bool = False):
+    """z ~ N(0, I) [N, Z] from the Philox stream (seed, offset) and x_hat = decoder(z) in ONE call
+    (psvae_sample_decode_f32 / _bf16; inference.py:22-25).  On the fused decode's shapes z is drawn inside the decode
+    kernel and never touches memory unless `want_z` / `z_out` asks for it; returns (x_hat, z or None)."""
+    dev = dec_params[0].device
+    xh = out if out is not None else torch.empty(N, D, dtype=torch.float32, device=dev)
+    L = _ffi.lib()
+    nbytes = int(L.psvae_decode_bf16_scratch_bytes(N, D, Z) if bf16 else L.psvae_decode_scratch_bytes(N))
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    arr = (C.c_void_p * 6)(*[_ffi.ptr(_f32(t, "decoder param")) for t in dec_params])
+    fn = L.psvae_sample_decode_bf16 if bf16 else L.psvae_sample_decode_f32
+    z = z_out if z_out is not None else (torch.empty(N, Z, dtype=torch.float32, device=dev) if want_z else None)
+    rc = fn(N, D, Z, seed, offset, arr, _ffi.ptr(z), _ffi.ptr(xh), _ffi.ptr(scratch), flags, _ffi.stream_ptr())
+    if rc == -1 and z is None:  # a shape the fused kernels do not cover: the draw needs a buffer
+        z = torch.empty(N, Z, dtype=torch.float32, device=dev)
+        rc = fn(N, D, Z, seed, offset, arr, _ffi.ptr(z), _ffi.ptr(xh), _ffi.ptr(scratch), flags, _ffi.stream_ptr())
+        z = z if want_z else None
+    _ffi.check(rc, "sample_decode")
+    return xh, z
+
+
 def last_step_launches_bf16() -> int:
     """launches of this thread's most recent bf16 pass (7 = the row-chain path at its default loss)"""
     return int(_ffi.lib().psvae_last_step_launches_bf16())

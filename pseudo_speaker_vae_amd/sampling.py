@@ -41,6 +41,14 @@ def unconditional_synthesis(vae_model, num_samples: int, device: str, seed: Opti
     """inference.py:10-27."""
     dim = _latent_dim(vae_model)
     key, off = _take_blocks((num_samples * dim + 3) // 4, seed)
+    model = getattr(vae_model, "model", vae_model)
+    if torch.device(device).type == "cuda" and hasattr(model, "ordered_params"):
+        # draw + decode as ONE call: on sampling-sized batches z is drawn inside the fused decode kernel (same Philox
+        # stream, same values as philox_normal followed by decode; no draw launch, no round trip of z through memory)
+        dec = [p.detach() for p in model.ordered_params()[12:]]
+        if dec[0].is_cuda:
+            xh, _ = ops.sample_decode(num_samples, dim, dec, model.input_dim, key, off, model.flags)
+            return xh.cpu()
     z = ops.philox_normal(num_samples * dim, key, off, device).view(num_samples, dim)
     with torch.no_grad():
         return vae_model.decode(z).detach().cpu()

@@ -158,3 +158,52 @@ def test_fused_bf16_decode_small_calls_keep_the_per_layer_path():
     assert torch.equal(a, b)
     ref = O.decode_bf16(p, z[-64:].cpu(), False)
     assert_close(a[-64:].cpu(), ref, BF16_TOL, "tail vs bf16 emulation", elementwise=False)
+
+
+@pytest.mark.parametrize("bf16,D,Z,N", [(False, 256, 64, 16384 + 37), (False, 512, 128, 20001), (False, 128, 32, 16400),
+                                        (True, 256, 64, 32768 + 77), (True, 512, 128, 40001), (True, 128, 32, 33000)])
+def test_sample_decode_draws_z_inside_the_fused_kernel(bf16, D, Z, N):
+    """psvae_sample_decode_*: unconditional_synthesis (inference.py:22-25) as ONE call -- z ~ N(0, I) drawn from the Philox
+    stream INSIDE the fused decode kernel.  The z it reports must be the stream psvae_philox_normal_f32 writes (same
+    blocks, same element order), and x_hat must be, bit for bit, what the same kernel decodes from that z read from
+    memory; rows past N are never written (guard rows behind both outputs)."""
+    from pseudo_speaker_vae_amd import ops
+    p = O.init_params(D, Z, 2)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    seed, off = 99, 12345
+    xg = torch.full((N + 1, D), float("nan"), device=DEV)
+    zg = torch.full((N + 1, Z), float("nan"), device=DEV)
+    xh, z = ops.sample_decode(N, Z, dec, D, seed, off, bf16=bf16, out=xg[:N], z_out=zg[:N])
+    torch.cuda.synchronize()
+    assert ops.last_decode_launches() == 4 or bf16          # (the fp32 entry counts its launches: fused = 4)
+    assert torch.isnan(xg[N]).all() and torch.isnan(zg[N]).all(), "wrote past the last row"
+    z_ref = ops.philox_normal(N * Z, seed, off, DEV).reshape(N, Z)
+    assert_close(z.cpu(), z_ref.cpu(), 1e-6, "in-kernel Philox draw vs psvae_philox_normal_f32")
+    assert_close(z[:64].cpu(), torch.from_numpy(O.philox_normal(64 * Z, seed, off).reshape(64, Z)), 1e-5, "draw vs oracle")
+    ref = (ops.decode_bf16 if bf16 else ops.decode)(z.contiguous(), dec, D)
+    torch.cuda.synchronize()
+    assert torch.equal(xh, ref), "decode of the drawn z differs from decode of the same z read from memory"
+    # without a z buffer the result is the same (z never touches memory)
+    xh2, none = ops.sample_decode(N, Z, dec, D, seed, off, bf16=bf16)
+    assert none is None and torch.equal(xh2, xh)
+    # another offset draws other rows
+    xh3, _ = ops.sample_decode(N, Z, dec, D, seed, off + N * Z // 4, bf16=bf16)
+    assert not torch.equal(xh3, xh)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_sample_decode_on_small_batches_draws_first(bf16):
+    """below the fused kernels' row counts the entry draws z with the Philox launch, then decodes: same numbers"""
+    from pseudo_speaker_vae_amd import ops
+    D, Z, N = 256, 64, 300
+    p = O.init_params(D, Z, 4)
+    dec = [p[k].to(DEV) for k in O.PARAM_KEYS[12:]]
+    xh, z = ops.sample_decode(N, Z, dec, D, 5, 40, bf16=bf16, want_z=True)
+    z_ref = ops.philox_normal(N * Z, 5, 40, DEV).reshape(N, Z)
+    assert torch.equal(z, z_ref)
+    ref = (ops.decode_bf16 if bf16 else ops.decode)(z_ref, dec, D)
+    assert torch.equal(xh, ref)
+    xh2, none = ops.sample_decode(N, Z, dec, D, 5, 40, bf16=bf16)
+    assert none is None and torch.equal(xh2, xh)
+    if not bf16:
+        assert_close(xh.cpu(), O.decode(p, z_ref.cpu()), 1e-4, "vs oracle")
