@@ -221,6 +221,15 @@ class Rank:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
+    def ranks_seen(self):
+        """how many ranks really took part: counted THROUGH the process group (a sum of ones), not read from the environment"""
+        if not self.use_dist:
+            return 1
+        import torch.distributed as dist
+        t = torch.ones(1, dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
     def close(self):
         if self.use_dist:
             import torch.distributed as dist
@@ -270,6 +279,7 @@ def bench_stub(args, rk: Rank):
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
             grad.mul_(1.0 / rk.world)
     wall, dev_ms = timed(rk, step, args.steps, args.warmup)
+    ranks_seen = rk.ranks_seen()
     if rk.rank == 0:
         print(json.dumps({
             "metric": "speaker-embeddings/sec (fwd+bwd)", "value": round(B * rk.world * args.steps / wall, 1),
@@ -277,7 +287,7 @@ def bench_stub(args, rk: Rank):
             "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "STUB (CPU/gloo rehearsal of the launcher and aggregation path; not a measurement)",
-                       "parallelism": f"dp{rk.world}", "allreduce": "gloo sum + scale"},
+                       "parallelism": f"dp{rk.world}", "allreduce": "gloo sum + scale", "ranks_seen": ranks_seen},
             "stub_grad_mean": float(grad[0])}), flush=True)
 
 
@@ -496,7 +506,7 @@ def run_rank(args) -> int:
     from pseudo_speaker_vae_amd.engine import TrainEngine
     D, Z, B = args.input_dim, args.latent_dim, args.batch
     eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=rk.pg, dtype=args.dtype,
-                      conditional=args.cond)
+                      conditional=args.cond, direct_allreduce=(args.allreduce == "direct") if rk.pg is not None else False)
     g = torch.Generator().manual_seed(1234 + rank)  # each rank its own shard of synthetic rows
     x = torch.randn(B, D, generator=g).to(dev)
     if args.cond:
@@ -526,12 +536,16 @@ def run_rank(args) -> int:
     mode = args.mode
     allreduce = "none"
     calibrated = None
-    if mode == "auto" and rk.pg is None and not args.with_adam:
+    direct = rk.pg is not None and eng.averager is not None and eng.averager.direct is not None
+    in_graph_env = os.environ.get("PSVAE_DDP_IN_GRAPH", "0") in ("1", "2") or os.environ.get("PSVAE_DDP_OVERLAP") == "1"
+    if mode == "auto" and not args.with_adam and not in_graph_env:
         # One GPU: the step can be issued as ONE C call that enqueues its launches on the stream ("eager") or replayed
         # as a captured HIP graph.  Both run the same kernels; a graph replay carries a fixed bubble of a few us per
         # launch of the graph, the eager form needs a host that stays ahead of the GPU.  Measure both for a moment
         # (untimed, before the warm-up steps) and take the faster one; config.launch says which, config.calibration
         # holds both figures.
+        # N > 1: the same two forms, each followed by ONE exchange of the flat gradient buffer; every rank measures both
+        # (the exchanges are collective), the decision is taken on the maximum over the ranks so that all ranks agree.
         eng.capture(x)
         def _time(fn, ms=120.0):
             torch.cuda.synchronize(dev)
@@ -545,9 +559,24 @@ def run_rank(args) -> int:
                 n += 100
                 torch.cuda.synchronize(dev)
             return (time.perf_counter() - t0) / n * 1e6
-        if gather is not None:
+        if rk.pg is not None:
+            def _time(fn, reps=300):  # (fixed counts: every rank must issue the same number of collectives)
+                rk.fence()
+                for _ in range(20):
+                    fn()
+                rk.fence()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                rk.fence()
+                return (time.perf_counter() - t0) / reps * 1e6
+        if gather is not None and rk.pg is None:
             t_graph = _time(lambda: (gather(0, eng.static_x), eng.replay()))
             t_eager = _time(lambda: (gather(0, x), eng.forward_backward(x)))
+        elif rk.pg is not None:
+            t_graph = _time(eng.replay)
+            t_eager = _time(lambda: eng.step_then_allreduce(x))
+            t_graph, t_eager = rk.max_over_ranks(t_graph, t_eager)
         else:
             t_graph = _time(eng.replay)
             t_eager = _time(lambda: eng.forward_backward(x))
@@ -577,12 +606,12 @@ def run_rank(args) -> int:
                     print(f"[bench] in-graph all-reduce unavailable ({type(e).__name__}: {e}); falling back", file=sys.stderr)
                 eng._collective_in_graph = False
                 mode = "graph+allreduce"
-                allreduce = "one ncclAvg over the flat gradient buffer after the graph"
+                allreduce = "one exchange of the flat gradient buffer after the graph"
                 eng.capture(x)
         else:
             if rk.pg is not None:
                 mode = "graph+allreduce"  # one captured step, then ONE RCCL all-reduce of the flat gradient buffer
-                allreduce = "one ncclAvg over the flat gradient buffer after the graph"
+                allreduce = "one exchange of the flat gradient buffer after the graph"
             if eng._graph is None or args.with_adam:
                 eng.capture(x, with_adam=args.with_adam and rk.pg is None)
 
@@ -595,19 +624,27 @@ def run_rank(args) -> int:
             if args.with_adam and not adam_in_graph:
                 eng.optimizer_step()
     else:
-        if rk.pg is not None:
+        if rk.pg is not None and args.mode == "eager":   # asked for explicitly: the phase-split form with two buckets
             allreduce = "2 buckets (decoder first), async under the encoder backward"
+        elif rk.pg is not None:
+            mode = "stream+allreduce"
+            allreduce = "one exchange of the flat gradient buffer behind the step on the same stream"
+        ddp_stream = rk.pg is not None and args.mode != "eager"
 
         def step(i):
             if gather is not None:
                 gather(i, x)
-            eng.forward_backward(x)
+            if ddp_stream:
+                eng.step_then_allreduce(x)
+            else:
+                eng.forward_backward(x)
             if args.with_adam:
                 eng.optimizer_step()
 
     prewarm(step, args, rk)
     wall, dev_ms = timed(rk, step, args.steps, args.warmup)
     loss = eng.loss3.detach().cpu().tolist()
+    ranks_seen = rk.ranks_seen()
 
     if rank == 0:
         traffic, traffic_source = committed_traffic(D, Z, B, args.dtype, plan)
@@ -632,7 +669,10 @@ def run_rank(args) -> int:
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
                        "launch": {"eager": "stream (one C call enqueues the step's launches)",
                                   "graph": "graph (captured HIP graph, one replay per step)"}.get(mode, mode),
-                       "n_gpus": world, "parallelism": f"dp{world}", "allreduce": allreduce,
+                       "n_gpus": world, "ranks_seen": ranks_seen, "parallelism": f"dp{world}",
+                       "allreduce": allreduce if rk.pg is None else allreduce + (
+                           " [direct: one-shot reduce-scatter + all-gather over IPC-mapped buffers, stream-ordered "
+                           "interprocess events (csrc/ipc_allreduce.hip)]" if direct else " [RCCL ncclAvg]"),
                        "batch_source": ("each step's rows gathered on the device from a shuffled packed table "
                                         "(psvae_gather_rows_f32, inside the timed step)") if args.gather else
                                        "one static batch resident in HBM (batch assembly is outside the timed step; --gather times it)",
@@ -671,6 +711,9 @@ def parse_args(argv=None):
                     help="train = cfg2 (headline); decode = cfg5 decode-only sampling; langevin = cfg5 conditional "
                          "sampling (Langevin chain + decode); --samples rows in total; api-step = the train shape "
                          "through PseudoSpeakerVAE.training_step + loss.backward() (the drop-in API path)")
+    ap.add_argument("--allreduce", choices=["rccl", "direct"], default=os.environ.get("PSVAE_BENCH_ALLREDUCE", "rccl"),
+                    help="N > 1: gradient exchange -- RCCL's all-reduce (default), or the direct one-shot reduce-scatter + "
+                         "all-gather over IPC-mapped buffers (csrc/ipc_allreduce.hip)")
     ap.add_argument("--gather", action="store_true",
                     help="train workload: assemble each step's batch from a packed embedding table in HBM inside the "
                          "timed step (a CommonVoice-sized table of synthetic rows, shuffled epoch order)")

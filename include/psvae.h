@@ -339,6 +339,26 @@ typedef struct psvae_adam_dev {
 int psvae_adam_step_dev_f32(const psvae_adam_dev* layout, psvae_adam_state* state /* device */, double beta1,
                             double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
+/* ---- direct gradient exchange between the ranks of one node (training.py:78: DDP's gradient mean) --------------------
+ * One-shot reduce-scatter + all-gather through buffers every rank maps from every other rank (hipIpcMemHandle): two hops,
+ * each a kernel that pulls 1/W of the payload from each peer over all xGMI links at once -- instead of RCCL's ring.
+ * Stream-ordered: the phases are separated by interprocess events (hipIpcEventHandle) the consumers' streams wait on; no
+ * kernel spins on a flag.  The hosts hand each other one sequence number per phase through a page of POSIX shared memory
+ * (so that a wait binds to THIS step's record), which makes the call not graph-capturable: enqueue it behind the step.
+ *   psvae_ipc_comm_create:  allocate this rank's buffers / events; blob_out (psvae_ipc_blob_bytes()) goes to every rank;
+ *                           `tag`: the same string on every rank, unique per communicator (names the shared page)
+ *   psvae_ipc_comm_connect: all_blobs = the `world` blobs in rank order
+ *   psvae_ipc_allreduce_avg_f32: g[0..nfloats) <- mean over ranks, in place, on `stream`; every rank calls it once per step.
+ *                           Ranks end with bit-identical values (each chunk is summed once, in rank order).  Returns
+ *                           PSVAE_ERR_STATE if a peer's host does not arrive within timeout_s.  nfloats % 4 == 0, g 16-B aligned.
+ * Exception to "the library allocates nothing": the exported buffers must come from hipMalloc in the exporting process. */
+typedef struct psvae_ipc_comm psvae_ipc_comm;
+size_t psvae_ipc_blob_bytes(void);
+int psvae_ipc_comm_create(int rank, int world, size_t nfloats, const char* tag, psvae_ipc_comm** out, void* blob_out);
+int psvae_ipc_comm_connect(psvae_ipc_comm* comm, const void* all_blobs);
+int psvae_ipc_allreduce_avg_f32(psvae_ipc_comm* comm, float* g, double timeout_s, void* stream);
+int psvae_ipc_comm_destroy(psvae_ipc_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

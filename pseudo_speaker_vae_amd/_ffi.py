@@ -33,6 +33,8 @@ SYMBOLS = (
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
     "psvae_last_decode_launches", "psvae_last_step_launches_bf16", "psvae_sample_decode_f32", "psvae_sample_decode_bf16",
+    "psvae_ipc_blob_bytes", "psvae_ipc_comm_create", "psvae_ipc_comm_connect", "psvae_ipc_allreduce_avg_f32",
+    "psvae_ipc_comm_destroy",
 )
 
 
@@ -161,6 +163,16 @@ def lib() -> C.CDLL:
     for fn in (L.psvae_sample_decode_f32, L.psvae_sample_decode_bf16):
         fn.argtypes = [i64, i64, i64, u64, u64, C.POINTER(vp), vp, vp, vp, u32, vp]
         fn.restype = C.c_int
+    L.psvae_ipc_blob_bytes.restype = C.c_size_t
+    L.psvae_ipc_blob_bytes.argtypes = []
+    L.psvae_ipc_comm_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp), vp]
+    L.psvae_ipc_comm_create.restype = C.c_int
+    L.psvae_ipc_comm_connect.argtypes = [vp, vp]
+    L.psvae_ipc_comm_connect.restype = C.c_int
+    L.psvae_ipc_allreduce_avg_f32.argtypes = [vp, vp, C.c_double, vp]
+    L.psvae_ipc_allreduce_avg_f32.restype = C.c_int
+    L.psvae_ipc_comm_destroy.argtypes = [vp]
+    L.psvae_ipc_comm_destroy.restype = C.c_int
     L.psvae_gather_rows_f32.argtypes = [vp, i64, i64, vp, i64, vp, vp]
     L.psvae_gather_rows_f32.restype = C.c_int
     f64 = C.c_double

@@ -15,12 +15,63 @@ import torch
 import torch.distributed as dist
 
 
+class DirectAllReduce:
+    """One-shot reduce-scatter + all-gather of a flat fp32 buffer between the ranks of ONE node through buffers every rank
+    maps from every other rank (csrc/ipc_allreduce.hip: hipIpcMemHandle + stream-ordered interprocess events; no kernel
+    spins on a flag) -- the direct form of DDP's gradient mean (training.py:78), two hops over all xGMI links instead of
+    RCCL's ring.  Setup moves one small blob per rank through torch.distributed (any backend); the exchange itself does
+    not touch torch.distributed.  Every rank ends with bit-identical values."""
+
+    _count = 0
+
+    def __init__(self, flat: torch.Tensor, process_group=None, timeout_s: float = 60.0):
+        import ctypes as C
+        import os
+        from . import _ffi
+        if not flat.is_cuda or flat.dtype != torch.float32 or not flat.is_contiguous() or flat.numel() % 4:
+            raise _ffi.PsvaeError("DirectAllReduce: a contiguous fp32 CUDA buffer of 4 k elements")
+        self.flat, self.pg, self.timeout_s = flat, process_group, float(timeout_s)
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        L = _ffi.lib()
+        DirectAllReduce._count += 1
+        tag = [f"{os.getpid()}-{DirectAllReduce._count}"]     # rank 0's pid + a counter: the same string on every rank
+        dist.broadcast_object_list(tag, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        nb = int(L.psvae_ipc_blob_bytes())
+        blob = C.create_string_buffer(nb)
+        comm = C.c_void_p()
+        torch.cuda.set_device(flat.device)
+        _ffi.check(L.psvae_ipc_comm_create(self.rank, self.world, flat.numel(), tag[0].encode(), C.byref(comm), blob),
+                   "ipc_comm_create")
+        self._comm = comm
+        blobs = [None] * self.world
+        dist.all_gather_object(blobs, bytes(blob.raw), group=process_group)
+        _ffi.check(L.psvae_ipc_comm_connect(comm, b"".join(blobs)), "ipc_comm_connect")
+        dist.barrier(group=process_group)                      # every rank has mapped every buffer
+
+    def allreduce(self):
+        """flat <- mean over the ranks, in place, on the current stream (every rank, once per step)"""
+        from . import _ffi
+        _ffi.check(_ffi.lib().psvae_ipc_allreduce_avg_f32(self._comm, self.flat.data_ptr(), self.timeout_s,
+                                                          _ffi.stream_ptr()), "ipc_allreduce")
+
+    def close(self):
+        from . import _ffi
+        if getattr(self, "_comm", None) is not None:
+            torch.cuda.synchronize(self.flat.device)
+            dist.barrier(group=self.pg)                        # nobody still reads what is about to be unmapped
+            _ffi.lib().psvae_ipc_comm_destroy(self._comm)
+            self._comm = None
+
+
 class GradAverager:
-    def __init__(self, flat: torch.Tensor, bucket_bounds: Sequence[int], process_group=None):
-        """flat: the flat gradient buffer; bucket_bounds: ascending offsets [0, b1, ..., len(flat)]."""
+    def __init__(self, flat: torch.Tensor, bucket_bounds: Sequence[int], process_group=None, direct: bool = False):
+        """flat: the flat gradient buffer; bucket_bounds: ascending offsets [0, b1, ..., len(flat)].
+        direct: average with DirectAllReduce (one node, CUDA buffers) instead of the backend's all-reduce."""
         assert bucket_bounds[0] == 0 and bucket_bounds[-1] == flat.numel()
         self.flat = flat
         self.pg = process_group
+        self.direct = DirectAllReduce(flat, process_group) if (direct and dist.is_initialized() and flat.is_cuda) else None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets: List[torch.Tensor] = [flat[a:b] for a, b in zip(bucket_bounds[:-1], bucket_bounds[1:])]
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
@@ -30,6 +81,10 @@ class GradAverager:
     def reduce_bucket(self, i: int):
         """start averaging bucket i (asynchronously); call once the kernels that WRITE it are enqueued"""
         if not dist.is_initialized():
+            return
+        if self.direct is not None:  # the direct exchange moves the whole buffer at once: with the LAST bucket
+            if i == 0:
+                self.direct.allreduce()
             return
         if self.backend == "nccl":  # RCCL: averaging inside the collective
             w = dist.all_reduce(self.buckets[i], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
@@ -41,6 +96,9 @@ class GradAverager:
     def reduce_all(self):
         """one collective over the whole flat buffer (fewer stream hand-offs than per-bucket overlap)"""
         if not dist.is_initialized():
+            return
+        if self.direct is not None:
+            self.direct.allreduce()
             return
         if self.backend == "nccl":
             # the blocking form (the current stream waits for the collective, the host does not): measured 31 us per

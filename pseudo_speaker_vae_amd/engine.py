@@ -93,7 +93,7 @@ class TrainEngine:
                  beta: float = 1.0, normalize_decoder: bool = False, use_cos_loss: bool = False,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  process_group=None, state_dict=None, dtype: str = "f32", conditional: bool = False,
-                 shard: Optional[tuple] = None, scheduler: Optional[dict] = None):
+                 shard: Optional[tuple] = None, scheduler: Optional[dict] = None, direct_allreduce: Optional[bool] = None):
         """dtype "bf16" = BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulate / master weights /
         gradients); conditional = one-hot gender+age gather tables (SURVEY.md section 8a row A9), either dtype;
         scheduler = CosineAnnealingLR keyword arguments {"T_max": .., "eta_min": ..} (lightning.py:206)."""
@@ -138,7 +138,10 @@ class TrainEngine:
             dst.copy_(s)
         self.loss3 = self.flat_grads[self.layout.loss_offset:self.layout.loss_offset + 3]
         # bucket 0 = encoders + loss scalars, bucket 1 = decoder (reduced first: its grads are ready first)
-        self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group) \
+        if direct_allreduce is None:  # PSVAE_DDP_DIRECT=1: the one-shot exchange over IPC buffers instead of RCCL's all-reduce
+            import os
+            direct_allreduce = os.environ.get("PSVAE_DDP_DIRECT") == "1"
+        self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group, direct=direct_allreduce) \
             if process_group is not None else None
         self.cond_tabs = self.layout.extra_views(self.flat_params)
         self.cond_gtabs = self.layout.extra_views(self.flat_grads)
@@ -203,6 +206,15 @@ class TrainEngine:
         self._forward_backward(x, eps, _local_only)
         if eps is None:
             self._skip_rng()
+
+    def step_then_allreduce(self, x: torch.Tensor):
+        """data-parallel step without a graph: ONE C call enqueues the whole local pass on the stream, then ONE exchange of
+        the flat gradient buffer (RCCL's all-reduce, or the direct IPC exchange) behind it on the same stream"""
+        self._forward_backward(x, None, _local_only=True)
+        self._skip_rng()
+        if self.averager is not None:
+            self.averager.reduce_all()
+            self.averager.wait()
 
     def _skip_rng(self):
         """jump over the other ranks' Philox blocks (a torch op: captured steps carry it)"""

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.psvae_version() == 3
+    assert lib.psvae_version() == 4
     assert b"NULL" in lib.psvae_strerror(-1)
     assert lib.psvae_strerror(0) == b"ok"
 

@@ -27,6 +27,7 @@ def test_self_launch_two_ranks_stub():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
     assert out["config"]["parallelism"] == "dp2" and "allreduce" in out["config"]
+    assert out["config"]["ranks_seen"] == 2      # counted through the process group, not read from the environment
     assert out["stub_grad_mean"] == 1.5  # mean of rank-valued "gradients" 1 and 2: the collective ran
     # rank 1 sleeps 2 ms per step, rank 0 1 ms: the reported time is the MAX over ranks
     assert out["ms_per_step"] >= 2.0

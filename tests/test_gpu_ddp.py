@@ -189,3 +189,92 @@ def test_two_ranks_on_one_gpu_over_gloo_average_like_one_full_batch_engine():
     for k, (o, s) in zip(full.keys, zip(lay.offsets, lay.shapes)):
         n = s.numel()
         assert_close(res[0]["graph_grads"][o:o + n], full.flat_grads[o:o + n].cpu(), 2e-5, "captured: shard mean " + k)
+
+
+# ---- the direct (IPC) gradient exchange: one-shot reduce-scatter + all-gather, stream-ordered interprocess events --------
+def _direct_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pseudo_speaker_vae_amd.ddp import DirectAllReduce
+        from pseudo_speaker_vae_amd.engine import TrainEngine
+        torch.cuda.set_device(0)
+        out = {}
+        # (1) the collective alone: ragged payload (not a multiple of world * 4), several steps back to back with NO host
+        #     synchronisation in between -- the stream-ordered events must keep the steps apart
+        n = 4 * 250_001
+        flat = torch.empty(n, device=DEV)
+        ar = DirectAllReduce(flat, dist.group.WORLD)
+        g = torch.Generator().manual_seed(100 + rank)
+        vals = [torch.randn(n, generator=g) for _ in range(4)]
+        dvals = [v.to(DEV) for v in vals]
+        res = []
+        for t in range(4):
+            flat.copy_(dvals[t])
+            ar.allreduce()
+            res.append(flat.clone())          # (stream-ordered: the clone is enqueued behind the exchange)
+        torch.cuda.synchronize()
+        out["coll"] = torch.stack([r.cpu() for r in res])
+        out["mine"] = torch.stack(vals)
+        ar.close()
+        if B % world == 0:
+            # (2) the training engine with the direct exchange in place of the backend all-reduce
+            gx = torch.Generator().manual_seed(11)
+            x = torch.randn(B, D, generator=gx)
+            rows = slice(rank * B // world, (rank + 1) * B // world)
+            eng = TrainEngine(D, Z, B // world, device=DEV, seed=5, beta=0.8, process_group=dist.group.WORLD,
+                              direct_allreduce=True)
+            assert eng.averager.direct is not None
+            eng.forward_backward(x[rows].to(DEV))
+            torch.cuda.synchronize()
+            out["eager_grads"] = eng.flat_grads.cpu().clone()
+            eng.capture(x[rows].to(DEV))
+            eng.replay()
+            eng.optimizer_step()
+            torch.cuda.synchronize()
+            out["graph_grads"] = eng.flat_grads.cpu().clone()
+            out["params"] = eng.flat_params.cpu().clone()
+            eng.averager.direct.close()
+        q.put((rank, {k: v.numpy() for k, v in out.items()}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_ipc_allreduce_between_processes_sharing_the_gpu(world):
+    """csrc/ipc_allreduce.hip with `world` processes on the one GPU: every rank maps every other rank's buffers
+    (hipIpcMemHandle), the phases are ordered by interprocess events on the streams (no spin-wait kernel); results equal
+    the mean computed on the host, all ranks bit-identical, four exchanges in flight back to back; then the training
+    engine over it equals one full-batch engine (as the gloo test above does for the backend all-reduce)."""
+    import torch.multiprocessing as mp
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in res.items()}
+    mean = sum(res[r]["mine"].double() for r in range(world)) / world
+    for r in range(world):
+        assert torch.equal(res[r]["coll"], res[0]["coll"]), f"rank {r} differs from rank 0"
+        for key in ("eager_grads", "graph_grads", "params"):
+            if key in res[0]:
+                assert torch.equal(res[r][key], res[0][key]), (r, key)
+    assert_close(res[0]["coll"], mean.float(), 2e-6, "direct all-reduce vs host mean", elementwise=False)
+    if B % world == 0:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, D, generator=g).to(DEV)
+        full = TrainEngine(D, Z, B, device=DEV, seed=5, beta=0.8)
+        full.forward_backward(x)
+        torch.cuda.synchronize()
+        lay = full.layout
+        for k, (o, s) in zip(full.keys, zip(lay.offsets, lay.shapes)):
+            n = s.numel()
+            assert_close(res[0]["eager_grads"][o:o + n], full.flat_grads[o:o + n].cpu(), 2e-5, "direct: mean of shard grads " + k)
