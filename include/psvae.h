@@ -255,6 +255,36 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
                        float noise_weight, int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset,
                        float* history, void* stream);
 
+/* The general head: everything LatentClassifier can be configured to with at most one hidden layer
+ * (latent_classifier.py:7-70) -- several labels (num_classes a dict: one output Linear per label on the shared trunk,
+ * stacked here into ONE [sum size, hidden] matrix W2 / [sum size] bias b2, or [sum size, Z] W1 when hidden == 0), the
+ * one-logit head (no gradient: inference.py:60-66 as written), activation 0 relu / 1 leaky_relu(0.01) / 2 tanh / 3 sigmoid,
+ * up to 32 classes in all.  The single-label ReLU C <= 8 case keeps its tuned entry points (psvae_langevin_f32,
+ * psvae_classifier_ce_f32). */
+typedef struct psvae_heads {
+    int32_t n_heads;      /* labels, 1..8 */
+    int32_t size[8];      /* classes per label */
+    int32_t target[8];    /* sampler: the label's target class in [0, size); unused by the cross-entropy step */
+    int32_t activation;
+    float prior_scale;    /* sampler: factor on the prior's gradient -z; 1, except for the reference's single one-logit head,
+                           * whose [N,1] + [N] broadcast (inference.py:62-64,90-92) sums the prior N times: pass N there
+                           * (0 is read as 1) */
+} psvae_heads;
+/* conditional_synthesis's loop (inference.py:72-103) scoring log p(y|z) as the SUM of the labels' log-probabilities
+ * (inference.py:80-84); arguments as psvae_langevin_f32 */
+int psvae_langevin_heads_f32(int64_t N, int64_t Z, int64_t hidden, const psvae_heads* heads, const float* W1, const float* b1,
+                             const float* W2, const float* b2, float* z, float step_size, float noise_weight,
+                             int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
+                             void* stream);
+/* the training step's classifier term (lightning.py:73-98): loss = MEAN over the labels of the mean-over-rows cross
+ * entropy (lightning.py:85-95), y = [n_heads][B] int64; loss_out[1 + 2 n_heads]: [0] = that loss, [1 + s] = rows whose
+ * argmax hits label s, [1 + n_heads + s] = mean cross entropy of label s alone; g_z, gW1 [rows1, Z], gb1, gW2 [sum size, hidden], gb2 as in psvae_classifier_ce_f32 (stacked like W2).
+ * scratch: psvae_classifier_scratch_bytes(B, hidden, sum size). */
+int psvae_classifier_heads_ce_f32(int64_t B, int64_t Z, int64_t hidden, const psvae_heads* heads, const float* z,
+                                  const int64_t* y, const float* W1, const float* b1, const float* W2, const float* b2,
+                                  float grad_scale, float* loss_out, float* g_z, float* gW1, float* gb1, float* gW2,
+                                  float* gb2, void* scratch, void* stream);
+
 /* kernel launches the calling thread's most recent bf16 pass (train step, forward or backward call) issued */
 int psvae_last_step_launches_bf16(void);
 

@@ -367,6 +367,72 @@ def philox_normal(n: int, seed: int, offset: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# The general LatentClassifier head (latent_classifier.py:7-70): a trunk of 0 or 1 hidden Linear + activation, one output
+# Linear per label (single-label heads are the one-label case).  Checker for csrc/heads_general.hip.
+# --------------------------------------------------------------------------------------
+_HEAD_ACTS = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+              "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.01)}
+
+
+def heads_forward(trunk, heads, z, activation: str = "relu"):
+    """trunk: [(W, b)] (0 or 1 entries), heads: [(W, b)] one per label -> list of logits (latent_classifier.py:58-68)"""
+    h = z
+    for W, b in trunk:
+        h = _HEAD_ACTS[activation](torch.addmm(b, h, W.t()))
+    return [torch.addmm(b, h, W.t()) for W, b in heads]
+
+
+def langevin_heads(trunk, heads, targets, activation, z0, noises, step_size: float, noise_weight: float,
+                   prior_scale: float = 1.0):
+    """inference.py:72-103 with log p(y|z) = sum over the targeted labels of log_softmax(logits_label)[target_label]
+    (inference.py:80-84); gradient by torch autograd on the CPU.  `heads` / `targets`: the labels the target names, in
+    the target dict's order.  prior_scale: N for the reference's single one-logit head (its [N,1] + [N] broadcast sums the
+    prior N times, inference.py:62-64,90-92), else 1; a one-logit head contributes no gradient (log_softmax == 0)."""
+    z = z0.clone()
+    hist = []
+    for t in range(noises.shape[0]):
+        zz = z.clone().requires_grad_()
+        lpy = 0.0
+        for logits, tgt in zip(heads_forward(trunk, heads, zz, activation), targets):
+            lp = torch.log_softmax(logits, dim=-1)
+            lpy = lpy + (lp[:, tgt] if lp.shape[1] > 1 else lp[:, 0] * (1.0 if tgt == 1 else -1.0))
+        total = (lpy - prior_scale * 0.5 * (zz ** 2).sum(dim=1)).sum()
+        grad = torch.autograd.grad(total, zz)[0]
+        z = z + 0.5 * step_size ** 2 * grad + step_size * noise_weight * noises[t]
+        hist.append(z.clone())
+    return z, hist
+
+
+def classifier_heads_ce(trunk, heads, z, ys, activation: str = "relu"):
+    """the training step's classifier term on its multi-label branch (lightning.py:85-95): the MEAN over the labels of the
+    mean-over-rows cross entropy; torch autograd on the CPU.  Returns loss, per-label losses, per-label hits, d loss / d z,
+    trunk gradients [(dW, db)], head gradients [(dW, db)]"""
+    zz = z.clone().requires_grad_()
+    tr = [(W.clone().requires_grad_(), b.clone().requires_grad_()) for W, b in trunk]
+    hd = [(W.clone().requires_grad_(), b.clone().requires_grad_()) for W, b in heads]
+    logits = heads_forward(tr, hd, zz, activation)
+    per = [torch.nn.functional.cross_entropy(l, y.long()) for l, y in zip(logits, ys)]
+    loss = sum(per) / len(per)
+    loss.backward()
+    hits = [int((l.argmax(1) == y).sum()) for l, y in zip(logits, ys)]
+    return (loss.detach(), [q.detach() for q in per], hits, zz.grad, [(W.grad, b.grad) for W, b in tr],
+            [(W.grad, b.grad) for W, b in hd])
+
+
+def train_step_with_label_heads(p, trunk, heads, x, ys, eps, beta: float = 1.0, cw: float = 1.0, activation: str = "relu",
+                                masks=None):
+    """lightning.py:67-131 with a (multi-label) LatentClassifier on mu: total = recon + beta kl + cw * mean_label CE.
+    Returns dict(total, recon, kl, ce, per_label, hits), the 18 VAE gradients, trunk and head gradients (times cw)."""
+    acts = forward(p, x, eps, False)
+    recon, kl, total = elbo(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False)
+    ce, per, hits, g_mu_cls, tg, hg = classifier_heads_ce(trunk, heads, acts["mu"], ys, activation)
+    g_xh, g_mu_d, g_lv_d = elbo_grads(acts["x_hat"], x, acts["mu"], acts["logvar"], beta, False, 1.0)
+    grads, _ = backward(p, x, acts, g_xh, g_mu_d + cw * g_mu_cls, g_lv_d, False, masks=masks)
+    return (dict(total=total + cw * ce, recon=recon, kl=kl, ce=ce, per_label=per, hits=hits, acts=acts), grads,
+            [(cw * gW, cw * gb) for gW, gb in tg], [(cw * gW, cw * gb) for gW, gb in hg])
+
+
+# --------------------------------------------------------------------------------------
 # Adam + CosineAnnealingLR  (lightning.py:204-214; torch.optim.Adam defaults)
 # --------------------------------------------------------------------------------------
 def adam_step(param, grad, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8,

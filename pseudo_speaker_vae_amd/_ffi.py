@@ -34,7 +34,7 @@ SYMBOLS = (
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
     "psvae_last_decode_launches", "psvae_last_step_launches_bf16", "psvae_sample_decode_f32", "psvae_sample_decode_bf16",
     "psvae_ipc_blob_bytes", "psvae_ipc_comm_create", "psvae_ipc_comm_connect", "psvae_ipc_allreduce_avg_f32",
-    "psvae_ipc_comm_destroy",
+    "psvae_ipc_comm_destroy", "psvae_langevin_heads_f32", "psvae_classifier_heads_ce_f32",
 )
 
 
@@ -67,6 +67,26 @@ class AdamDev(C.Structure):
                 ("exp_avg_sq", C.c_void_p), ("mat_off", C.c_int64 * 9), ("mat_rows", C.c_int64 * 9),
                 ("mat_cols", C.c_int64 * 9), ("vec_off", C.c_int64 * 16), ("vec_len", C.c_int64 * 16),
                 ("n_vec", C.c_int32)]
+
+
+class Heads(C.Structure):
+    """psvae_heads: the labels of a (multi-label) LatentClassifier head, output Linears stacked"""
+    _fields_ = [("n_heads", C.c_int32), ("size", C.c_int32 * 8), ("target", C.c_int32 * 8), ("activation", C.c_int32),
+                ("prior_scale", C.c_float)]
+
+
+ACTIVATION_IDS = {"relu": 0, "leaky_relu": 1, "tanh": 2, "sigmoid": 3}
+
+
+def make_heads(sizes, targets=None, activation: str = "relu", prior_scale: float = 1.0) -> Heads:
+    h = Heads()
+    h.prior_scale = float(prior_scale)
+    h.n_heads = len(sizes)
+    for i, n in enumerate(sizes):
+        h.size[i] = int(n)
+        h.target[i] = int(targets[i]) if targets is not None else 0
+    h.activation = ACTIVATION_IDS[activation]
+    return h
 
 
 class Mlp3Grads(C.Structure):
@@ -163,6 +183,11 @@ def lib() -> C.CDLL:
     for fn in (L.psvae_sample_decode_f32, L.psvae_sample_decode_bf16):
         fn.argtypes = [i64, i64, i64, u64, u64, C.POINTER(vp), vp, vp, vp, u32, vp]
         fn.restype = C.c_int
+    L.psvae_langevin_heads_f32.argtypes = [i64, i64, i64, C.POINTER(Heads), vp, vp, vp, vp, vp, f32, f32, i64, vp, u64, u64, vp, vp]
+    L.psvae_langevin_heads_f32.restype = C.c_int
+    L.psvae_classifier_heads_ce_f32.argtypes = [i64, i64, i64, C.POINTER(Heads), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp,
+                                                vp, vp, vp, vp]
+    L.psvae_classifier_heads_ce_f32.restype = C.c_int
     L.psvae_ipc_blob_bytes.restype = C.c_size_t
     L.psvae_ipc_blob_bytes.argtypes = []
     L.psvae_ipc_comm_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(vp), vp]

@@ -1021,10 +1021,70 @@ int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const fl
     return 0;
 }
 
+int psvae_langevin_heads_f32(int64_t N, int64_t Z, int64_t hidden, const psvae_heads* heads, const float* W1, const float* b1,
+                             const float* W2, const float* b2, float* z, float step_size, float noise_weight,
+                             int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
+                             void* stream) {
+    if (!heads || !W1 || !b1 || !z) return PSVAE_ERR_NULL;
+    if (hidden > 0 && (!W2 || !b2)) return PSVAE_ERR_NULL;
+    if (N <= 0 || num_steps < 0 || hidden < 0 || hidden > 128) return PSVAE_ERR_SHAPE;
+    if (!(Z == 16 || Z == 32 || Z == 64 || Z == 128)) return PSVAE_ERR_SHAPE;
+    if (heads->n_heads < 1 || heads->n_heads > 8 || heads->activation < 0 || heads->activation > 3) return PSVAE_ERR_ARG;
+    int ct = 0;
+    for (int s = 0; s < heads->n_heads; ++s) {
+        if (heads->size[s] < 1) return PSVAE_ERR_SHAPE;
+        if (heads->target[s] < 0 || heads->target[s] >= heads->size[s]) return PSVAE_ERR_ARG;
+        ct += heads->size[s];
+    }
+    if (ct > 32) return PSVAE_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(noises) & 15) ||
+        (reinterpret_cast<uintptr_t>(history) & 15))
+        return PSVAE_ERR_ALIGN;
+    RET_IF(launch_langevin_general(N, (int)Z, (int)hidden, heads, W1, b1, W2, b2, z, step_size, noise_weight, num_steps,
+                                   noises, seed, offset, history, (hipStream_t)stream));
+    return 0;
+}
+
+int psvae_classifier_heads_ce_f32(int64_t B, int64_t Z, int64_t hidden, const psvae_heads* heads, const float* z,
+                                  const int64_t* y, const float* W1, const float* b1, const float* W2, const float* b2,
+                                  float grad_scale, float* loss_out, float* g_z, float* gW1, float* gb1, float* gW2,
+                                  float* gb2, void* scratch, void* stream) {
+    if (!heads || !z || !y || !W1 || !b1 || !loss_out || !g_z || !gW1 || !gb1 || !scratch) return PSVAE_ERR_NULL;
+    if (hidden > 0 && (!W2 || !b2 || !gW2 || !gb2)) return PSVAE_ERR_NULL;
+    if (B <= 0 || hidden < 0 || hidden > 128) return PSVAE_ERR_SHAPE;
+    if (!(Z == 16 || Z == 32 || Z == 64 || Z == 128)) return PSVAE_ERR_SHAPE;
+    if (heads->n_heads < 1 || heads->n_heads > 8 || heads->activation < 0 || heads->activation > 3) return PSVAE_ERR_ARG;
+    int C = 0;
+    for (int s = 0; s < heads->n_heads; ++s) {
+        if (heads->size[s] < 1) return PSVAE_ERR_SHAPE;
+        C += heads->size[s];
+    }
+    if (C > 32) return PSVAE_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(g_z) & 15)) return PSVAE_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    char* base = reinterpret_cast<char*>(scratch);
+    const size_t hb = align_up((size_t)B * (hidden > 0 ? hidden : 1) * sizeof(float), 256);
+    float* h = reinterpret_cast<float*>(base);
+    float* dh = reinterpret_cast<float*>(base + hb);
+    float* dl = reinterpret_cast<float*>(base + 2 * hb);
+    float* partials = reinterpret_cast<float*>(base + 2 * hb + align_up((size_t)B * C * sizeof(float), 256));
+    RET_IF(launch_classifier_ce_general(B, (int)Z, (int)hidden, heads, z, y, W1, b1, W2, b2, grad_scale / (float)B, h, dh, dl,
+                                        g_z, partials, loss_out, s));
+    GemmBatch b{};
+    if (hidden > 0) {
+        add(b, make_desc(GK_TN, C, (int)hidden, (int)B, dl, C, h, (int)hidden, gW2, (int)hidden, EPI_NONE, nullptr, gb2));
+        add(b, make_desc(GK_TN, (int)hidden, (int)Z, (int)B, dh, (int)hidden, z, (int)Z, gW1, (int)Z, EPI_NONE, nullptr, gb1));
+    } else {
+        add(b, make_desc(GK_TN, C, (int)Z, (int)B, dl, C, z, (int)Z, gW1, (int)Z, EPI_NONE, nullptr, gb1));
+    }
+    RET_IF(launch_gemm_batch(b, 0, s));
+    return 0;
+}
+
 size_t psvae_classifier_scratch_bytes(int64_t B, int64_t hidden, int64_t C) {
     if (B <= 0 || C <= 0 || hidden < 0) return 0;
     return 2 * align_up((size_t)B * (hidden > 0 ? hidden : 1) * sizeof(float), 256) +
-           align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)2 * classifier_blocks(B) * sizeof(float), 256);
+           align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)17 * classifier_blocks(B) * sizeof(float), 256);  // (17: loss + 8 labels' hits + 8 labels' losses per block in the general step)
 }
 
 int psvae_classifier_ce_f32(int64_t B, int64_t Z, int64_t hidden, int64_t C, const float* z, const int64_t* y,

@@ -288,6 +288,15 @@ hipError_t launch_classifier_ce(int64_t B, int Z, int hidden, int C, const float
                                 const float* b1, const float* W2, const float* b2, float scale, float* h_out,
                                 float* dh_out, float* dlogits, float* g_z, float* partials, float* loss2, hipStream_t s,
                                 int relu_input = 0);
+// heads_general.hip: multi-label / non-ReLU / up to 32 classes
+hipError_t launch_langevin_general(int64_t N, int Z, int hidden, const psvae_heads* heads, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, float* z, float step_size, float noise_weight,
+                                   int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,
+                                   hipStream_t s);
+hipError_t launch_classifier_ce_general(int64_t B, int Z, int hidden, const psvae_heads* heads, const float* z, const int64_t* y,
+                                        const float* W1, const float* b1, const float* W2, const float* b2, float scale,
+                                        float* h_out, float* dh_out, float* dlogits, float* g_z, float* partials,
+                                        float* loss_out, hipStream_t s);
 hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1, const float* b1, const float* W2,
                            const float* b2, float* z, int target, float step_size, float noise_weight,
                            int64_t num_steps, const float* noises, uint64_t seed, uint64_t offset, float* history,

@@ -111,6 +111,72 @@ class _ClassifierCEFunction(torch.autograd.Function):
         return (g_z, None, None, *grads)
 
 _ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "leaky_relu": nn.LeakyReLU}
+_ACT_NAME = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid", nn.LeakyReLU: "leaky_relu"}
+
+
+def classifier_heads_ce_raw(z, ys, hidden, activation, sizes, trunk, heads, grad_scale: float = 1.0):
+    """psvae_classifier_heads_ce_f32 on detached tensors (any head LatentClassifier.general_spec covers): trunk = [W1, b1]
+    or [] (no hidden layer), heads = [(W, b) per label]; ys = the labels' targets, one [B] tensor per label.  Returns
+    loss_out = {mean over labels of the mean CE, hits per label, mean CE per label}, g_z, the trunk's gradients and the
+    heads' gradients [(gW, gb) per label], all times grad_scale."""
+    import ctypes as C
+    z = z.detach().float().contiguous()
+    B, Z = z.shape
+    n = len(sizes)
+    y = torch.stack([t.to(device=z.device, dtype=torch.int64) for t in ys]).contiguous()
+    Wc = torch.cat([W.detach().float() for W, _ in heads]).contiguous()     # the labels' output Linears, stacked
+    bc = torch.cat([b.detach().float() for _, b in heads]).contiguous()
+    Ct = Wc.shape[0]
+    for k, (t, c) in enumerate(zip(ys, sizes)):
+        label_watch.before(t, c, f"LatentClassifier cross entropy (label {k})")
+    lib = _ffi.lib()
+    spec = _ffi.make_heads(sizes, None, activation)
+    scratch = torch.empty(int(lib.psvae_classifier_scratch_bytes(B, hidden, Ct)), dtype=torch.uint8, device=z.device)
+    loss_out = torch.empty(1 + 2 * n, dtype=torch.float32, device=z.device)
+    g_z = torch.empty_like(z)
+    if hidden:
+        W1, b1 = (t.detach().float().contiguous() for t in trunk)
+        gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(Wc), torch.empty_like(bc)
+        args = (_ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(Wc), _ffi.ptr(bc))
+        gargs = (_ffi.ptr(gW1), _ffi.ptr(gb1), _ffi.ptr(gW2), _ffi.ptr(gb2))
+    else:
+        gW1, gb1 = torch.empty_like(Wc), torch.empty_like(bc)
+        gW2 = gb2 = None
+        args = (_ffi.ptr(Wc), _ffi.ptr(bc), None, None)
+        gargs = (_ffi.ptr(gW1), _ffi.ptr(gb1), None, None)
+    _ffi.check(lib.psvae_classifier_heads_ce_f32(B, Z, hidden, C.byref(spec), _ffi.ptr(z), _ffi.ptr(y), *args,
+                                                 float(grad_scale), _ffi.ptr(loss_out), _ffi.ptr(g_z), *gargs,
+                                                 _ffi.ptr(scratch), _ffi.stream_ptr()), "classifier_heads_ce")
+    label_watch.after(loss_out[0], y, max(sizes), "LatentClassifier cross entropy (multi-label)")
+    gWc, gbc = (gW2, gb2) if hidden else (gW1, gb1)
+    head_grads = list(zip(gWc.split(list(sizes)), gbc.split(list(sizes))))
+    return loss_out, g_z, ([gW1, gb1] if hidden else []), head_grads
+
+
+class _ClassifierHeadsCEFunction(torch.autograd.Function):
+    """loss_out = CE step of a general head (several labels / any of the four activations / up to 32 classes) as ONE
+    autograd node: forward runs the fused step with grad_scale = 1, backward hands the gradients out scaled by the
+    upstream d(loss_out[0]) on the device.  params = trunk (0 or 2 tensors) then (W, b) per label."""
+
+    @staticmethod
+    def forward(ctx, z, ys, meta, *params):
+        hidden, activation, sizes = meta
+        nt = 2 if hidden else 0
+        trunk, flat = params[:nt], params[nt:]
+        heads = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(sizes))]
+        loss_out, g_z, tg, hg = classifier_heads_ce_raw(z, ys, hidden, activation, sizes, trunk, heads)
+        ctx.g_z = g_z
+        ctx.grads = list(tg) + [t for pair in hg for t in pair]
+        return loss_out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        s = g_out[0].float()  # only the mean loss is differentiable (hits and per-label losses are reports)
+        g_z = ctx.g_z.mul_(s) if ctx.needs_input_grad[0] else None
+        grads = [g.contiguous().mul_(s) for g in ctx.grads]
+        ctx.g_z = ctx.grads = None
+        return (g_z, None, None, *grads)
+
 
 
 class LatentClassifier(nn.Module):
@@ -157,6 +223,47 @@ class LatentClassifier(nn.Module):
         if lins[-1].out_features > 8 or hidden > 128 or lins[0].in_features not in (16, 32, 64, 128):
             return None
         return hidden, [p for l in lins for p in (l.weight, l.bias)]
+
+    def general_spec(self):
+        """(hidden, activation, label names, sizes, trunk params, [(W, b) per label]) when the GENERAL fused kernels
+        (csrc/heads_general.hip) cover this head: one or two Linear layers, any of the four activations, one label or
+        several, at most 32 classes in all and 8 labels, hidden <= 128, input dim in {16, 32, 64, 128}; else None"""
+        lins = [m for m in self.layers if isinstance(m, nn.Linear)]
+        acts = [m for m in self.layers if not isinstance(m, nn.Linear)]
+        if self.single_label_mode:
+            if len(lins) not in (1, 2):
+                return None
+            trunk, heads, names = lins[:-1], [lins[-1]], [None]
+        else:
+            if len(lins) > 1:
+                return None
+            trunk, names = lins, list(self.output_layers.keys())
+            heads = [self.output_layers[k] for k in names]
+        if any(type(a) not in _ACT_NAME for a in acts) or len({type(a) for a in acts}) > 1:
+            return None
+        if acts and isinstance(acts[0], nn.LeakyReLU) and acts[0].negative_slope != 0.01:
+            return None
+        activation = _ACT_NAME[type(acts[0])] if acts else "relu"
+        hidden = trunk[0].out_features if trunk else 0
+        zin = (trunk[0] if trunk else heads[0]).in_features
+        sizes = [h.out_features for h in heads]
+        if sum(sizes) > 32 or len(sizes) > 8 or hidden > 128 or zin not in (16, 32, 64, 128):
+            return None
+        tp = [trunk[0].weight, trunk[0].bias] if trunk else []
+        return hidden, activation, names, sizes, tp, [(h.weight, h.bias) for h in heads]
+
+    def cross_entropy_heads_step(self, z: torch.Tensor, y):
+        """The training step's classifier term for ANY head general_spec covers, as one fused autograd node
+        (lightning.py:73-98): y a [B] tensor (single label) or a dict label -> [B] (multi-label, lightning.py:85-95: the
+        MEAN of the labels' cross entropies).  Returns (loss, {label: hits}, {label: that label's mean CE})."""
+        spec = self.general_spec()
+        if spec is None or not z.is_cuda:
+            raise _ffi.PsvaeError("cross_entropy_heads_step: a head LatentClassifier.general_spec() covers, on the GPU")
+        hidden, activation, names, sizes, trunk, heads = spec
+        ys = [y] if names == [None] else [y[k] for k in names]
+        out = _ClassifierHeadsCEFunction.apply(z, ys, (hidden, activation, tuple(sizes)), *trunk, *[t for p in heads for t in p])
+        n = len(sizes)
+        return out[0], {k: out[1 + i] for i, k in enumerate(names)}, {k: out[1 + n + i] for i, k in enumerate(names)}
 
     def cross_entropy_step(self, z: torch.Tensor, y: torch.Tensor):
         """(mean cross entropy, number of correct rows) of this head on latent rows z[B, Z] against labels y[B] in

@@ -177,6 +177,21 @@ class PseudoSpeakerVAE(_Base):
                     self.log(f"{prefix}_classifier_acc", hits / x.size(0), sync_dist=True)
                     self.log(f"{prefix}_classifier_loss", classifier_loss, sync_dist=True)
                     y_hat = None
+                elif (mu.is_cuda and isinstance(y, dict) == self.multilabel and self.classifier.general_spec() is not None):
+                    # the general fused step (csrc/heads_general.hip): several labels (the MEAN of their cross
+                    # entropies, lightning.py:85-95), tanh / sigmoid / leaky-ReLU trunks, up to 32 classes
+                    fused_head = True
+                    classifier_loss, hits, per_label = self.classifier.cross_entropy_heads_step(mu, y)
+                    if not self.multilabel:
+                        self.log(f"{prefix}_classifier_acc", hits[None] / x.size(0), sync_dist=True)
+                        self.log(f"{prefix}_classifier_loss", classifier_loss, sync_dist=True)
+                    else:
+                        running = 0  # (the reference logs the labels' RUNNING sum under each label's key, lightning.py:93)
+                        for name in per_label:
+                            running = running + per_label[name]
+                            self.log(f"{prefix}_classifier_acc_{name}", hits[name] / x.size(0), sync_dist=True)
+                            self.log(f"{prefix}_classifier_loss_{name}", running, sync_dist=True)
+                    y_hat = None
                 else:
                     y_hat = self.classifier(mu)
                 if fused_head:

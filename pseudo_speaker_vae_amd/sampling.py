@@ -79,6 +79,8 @@ def _fusable_classifier(clf, target):
     hidden = lins[0].out_features if len(lins) == 2 else 0
     if C > 8 or hidden > 128 or lins[0].in_features not in (16, 32, 64, 128) or not (0 <= target < C):
         return None
+    if C == 1:  # the one-logit head has the reference's N-fold prior (see _general_classifier): the general kernel's case
+        return None
     w = [p.detach().float().contiguous() for l in lins for p in (l.weight, l.bias)]
     return (w[0], w[1], w[2] if hidden else None, w[3] if hidden else None, hidden, C)
 
@@ -98,6 +100,65 @@ def langevin_fused(clf_params, z: torch.Tensor, target: int, step_size: float, n
     return z, hist
 
 
+def _general_classifier(clf, target, num_samples: int = 1):
+    """(hidden, activation, sizes, targets, [W1, b1, W2, b2], prior_scale) for the general fused Langevin kernel (csrc/heads_general.hip):
+    several labels (dict target: the labels named in it, inference.py:80-84), any of the four activations, the one-logit
+    head, up to 32 classes; None when the head has more than one hidden layer (the torch-op loop below serves those)."""
+    spec = clf.general_spec() if clf is not None and hasattr(clf, "general_spec") else None
+    if spec is None:
+        return None
+    hidden, activation, names, sizes, trunk, heads = spec
+    if names == [None]:
+        if not isinstance(target, int):
+            return None
+        pick, targets = [0], [target]
+    else:
+        if not isinstance(target, dict) or any(k not in names for k in target):
+            return None
+        pick = [names.index(k) for k in target]
+        targets = [int(target[k]) for k in target]
+    sizes = [sizes[i] for i in pick]
+    prior_scale = 1.0
+    for t, c in zip(targets, sizes):
+        if c == 1:
+            # The reference's binary branch (inference.py:60-66): log-softmax over ONE logit is identically 0, so the head
+            # has no gradient; its [N, 1] result is then added to the [N] prior term (inference.py:92), which broadcasts
+            # to [N, N] and sums the prior N times -- kept as written (SURVEY Appendix B: quirks are not fixed silently).
+            # Inside a dict target the reference's in-place add raises on those shapes: the torch-op loop is left to do so.
+            if names != [None]:
+                return None
+            if t not in (0, 1):
+                raise ValueError("classifier_target must be 0 or 1 for binary classifier")  # inference.py:66
+            prior_scale = float(num_samples)
+        elif not 0 <= t < c:
+            return None
+    targets = [0 if c == 1 else t for t, c in zip(targets, sizes)]
+    Wc = torch.cat([heads[i][0].detach().float() for i in pick]).contiguous()
+    bc = torch.cat([heads[i][1].detach().float() for i in pick]).contiguous()
+    if hidden:
+        w = [trunk[0].detach().float().contiguous(), trunk[1].detach().float().contiguous(), Wc, bc]
+    else:
+        w = [Wc, bc, None, None]
+    return hidden, activation, sizes, targets, w, prior_scale
+
+
+def langevin_general(spec, z: torch.Tensor, step_size: float, noise_weight: float, num_steps: int, noises=None, seed: int = 0,
+                     offset: int = 0, return_history: bool = False):
+    """psvae_langevin_heads_f32: the whole chain in one kernel for any head _general_classifier accepts"""
+    import ctypes as C
+    hidden, activation, sizes, targets, (W1, b1, W2, b2), prior_scale = spec
+    z = z.detach().float().contiguous().clone()
+    N, Z = z.shape
+    hist = torch.empty(num_steps, N, Z, dtype=torch.float32, device=z.device) if return_history else None
+    nz = None if noises is None else noises.to(device=z.device, dtype=torch.float32).contiguous()
+    heads = _ffi.make_heads(sizes, targets, activation, prior_scale)
+    _ffi.check(_ffi.lib().psvae_langevin_heads_f32(N, Z, hidden, C.byref(heads), _ffi.ptr(W1), _ffi.ptr(b1), _ffi.ptr(W2),
+                                                   _ffi.ptr(b2), _ffi.ptr(z), float(step_size), float(noise_weight),
+                                                   int(num_steps), _ffi.ptr(nz), seed, offset, _ffi.ptr(hist),
+                                                   _ffi.stream_ptr()), "langevin_heads")
+    return z, hist
+
+
 def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[int, dict], step_size: float = 0.01,
                           num_steps: int = 100, noise_weight: float = 1.0, return_history: bool = False,
                           device: str = "cpu", z0: Optional[torch.Tensor] = None, noises=None):
@@ -109,6 +170,19 @@ def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[
                            "pass device='cuda' (inference.py --device cuda) with the model moved there")
     dim = _latent_dim(vae_model)
     fus = _fusable_classifier(getattr(vae_model, "classifier", None), classifier_target)
+    gen = None if fus is not None else _general_classifier(getattr(vae_model, "classifier", None), classifier_target, num_samples)
+    if gen is not None and dim in (16, 32, 64, 128):
+        # general fused path: multi-label / non-ReLU / one-logit / up to 32 classes, still ONE kernel for the whole chain
+        nblk = (num_samples * dim + 3) // 4
+        key, off = _take_blocks((1 + num_steps) * nblk)
+        z_init = ops.philox_normal(num_samples * dim, key, off, device).view(num_samples, dim) if z0 is None else z0.to(device)
+        z, hist = langevin_general(gen, z_init, step_size, noise_weight, num_steps, noises, seed=key, offset=off + nblk,
+                                   return_history=return_history)
+        with torch.no_grad():
+            x_hat = vae_model.decode(z).detach().cpu()
+        if return_history:
+            return x_hat, list(hist.cpu().numpy())
+        return x_hat
     if fus is not None and torch.device(device).type == "cuda":
         # fused HIP path: z0 and the per-step noise from the samplers' device Philox stream (follows torch.manual_seed;
         # every call consumes (1 + num_steps) * nblk fresh blocks)
@@ -122,8 +196,8 @@ def conditional_synthesis(vae_model, num_samples: int, classifier_target: Union[
         if return_history:
             return x_hat, list(hist.cpu().numpy())
         return x_hat
-    # general path (multi-label heads, other activations, deeper classifiers): the reference's loop on the
-    # device with torch ops, still without per-step host synchronisation
+    # what is left for torch ops: heads with more than one hidden layer (or > 32 classes, hidden > 128): the reference's loop
+    # on the device, still without per-step host synchronisation
     z = (torch.randn((num_samples, dim), device=device) if z0 is None else z0.to(device)).requires_grad_()
     history = []
     for t in range(num_steps):

@@ -318,6 +318,113 @@ def make_langevin_case(name, D, Z, N, steps, target, step_size, noise_weight, nu
     print(name, "ok")
 
 
+def _ref_general_classifier(Z, num_classes, num_layers, hidden, activation, scale, seed):
+    """the REFERENCE's LatentClassifier (latent_classifier.py:7-70) in a configuration its Lightning module cannot build as
+    written (lightning.py:39 reads classifier_hparams['label_classes'], a key LatentClassifier does not accept): constructed
+    from the reference's own class, unmodified, and attached to the module afterwards"""
+    from ps_vae.latent_classifier import LatentClassifier as RefLC
+    assert os.path.realpath(sys.modules[RefLC.__module__].__file__).startswith(REF)
+    torch.manual_seed(seed)
+    clf = RefLC(Z, num_classes, num_layers=num_layers, hidden_dim=hidden, activation=activation)
+    with torch.no_grad():
+        for p in clf.parameters():
+            p.mul_(scale)
+    return clf
+
+
+def _save_classifier(fx, clf, names):
+    lins = [l for l in clf.layers if isinstance(l, nn.Linear)]
+    fx["n_trunk"] = len(lins) if names is not None else len(lins) - 1
+    trunk = lins if names is not None else lins[:-1]
+    for i, l in enumerate(trunk):
+        fx[f"trunk_w{i}"] = l.weight.detach().numpy()
+        fx[f"trunk_b{i}"] = l.bias.detach().numpy()
+    heads = [clf.output_layers[k] for k in names] if names is not None else [lins[-1]]
+    for i, l in enumerate(heads):
+        fx[f"head_w{i}"] = l.weight.detach().numpy()
+        fx[f"head_b{i}"] = l.bias.detach().numpy()
+    return trunk, heads
+
+
+def make_langevin_general_case(name, D, Z, N, steps, num_classes, target, num_layers, hidden, activation, step_size,
+                               noise_weight):
+    """the reference's conditional_synthesis (inference.py:29-110, unmodified) driving the reference's LatentClassifier in
+    the configurations the general fused kernel covers: several labels (dict target), the one-logit head, non-ReLU trunks"""
+    torch.manual_seed(3)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z, normalize_decoder=False))
+    mod.classifier = _ref_general_classifier(Z, num_classes, num_layers, hidden, activation, 4.0, 17)
+    torch.manual_seed(11)
+    xh, hist = ref_inference.conditional_synthesis(
+        mod, num_samples=N, classifier_target=target, step_size=step_size, num_steps=steps,
+        noise_weight=noise_weight, return_history=True, device="cpu")
+    torch.manual_seed(11)
+    z0 = torch.randn(N, Z)
+    noises = torch.stack([torch.randn(N, Z) for _ in range(steps)])
+    multi = isinstance(num_classes, dict)
+    names = list(num_classes.keys()) if multi else None
+    fx = dict(D=D, Z=Z, N=N, steps=steps, step_size=step_size, noise_weight=noise_weight, pseed=3, z0=z0.numpy(),
+              noises=noises.numpy(), hist=np.stack(hist), x_hat=xh.numpy(), num_layers=num_layers, hidden=hidden,
+              activation=np.array(activation), multi=int(multi),
+              names=np.array(names if multi else ["-"]), sizes=np.array(list(num_classes.values()) if multi else [num_classes]),
+              target_names=np.array(list(target.keys()) if multi else ["-"]),
+              target_vals=np.array(list(target.values()) if multi else [target]))
+    _save_classifier(fx, mod.classifier, names)
+    op = O.init_params(D, Z, 3)
+    for k in O.PARAM_KEYS:
+        assert torch.equal(dict(mod.model.named_parameters())[k].detach(), op[k]), k
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(name, "ok")
+
+
+def make_multilabel_step_case(name, D, Z, B, num_classes, num_layers, hidden, activation, cw, beta=1.0):
+    """the reference's training_step (lightning.py:67-131, unmodified) on its multi-label branch (85-95).  The module
+    cannot be BUILT multi-label as written (lightning.py:39, 95: `label_classes`), so the reference's classifier is
+    attached after construction with the attributes those lines read: multilabel, accuracy[label], classifier.label_classes."""
+    torch.manual_seed(5)
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z, normalize_decoder=False), kl_loss_weight=beta,
+                           classifier_loss_weight=cw)
+    clf = _ref_general_classifier(Z, num_classes, num_layers, hidden, activation, 3.0, 19)
+    clf.label_classes = dict(num_classes)
+    mod.classifier = clf
+    mod.multilabel = True
+    mod.accuracy = nn.ModuleDict({k: Accuracy() for k in num_classes})
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, D, generator=g)
+    y = {k: torch.randint(0, n, (B,), generator=g) for k, n in num_classes.items()}
+    torch.manual_seed(2200)
+    out = mod.training_step((x, y), 0)
+    torch.manual_seed(2200)
+    eps = torch.randn(B, Z)
+    out["loss"].backward()
+    names = list(num_classes.keys())
+    fx = dict(D=D, Z=Z, B=B, pseed=5, beta=beta, cw=cw, hidden=hidden, num_layers=num_layers, activation=np.array(activation),
+              names=np.array(names), sizes=np.array(list(num_classes.values())), x=x.numpy(), eps=eps.numpy(),
+              total=np.float64(out["loss"].item()), recon=np.float64(mod._logged["train_recon_loss"]),
+              kl=np.float64(mod._logged["train_kl_loss"]))
+    for k in names:
+        fx[f"y_{k}"] = y[k].numpy()
+        fx[f"logged_loss_{k}"] = np.float64(mod._logged[f"train_classifier_loss_{k}"])  # the RUNNING sum (lightning.py:93)
+        fx[f"logged_acc_{k}"] = np.float64(mod._logged[f"train_classifier_acc_{k}"])
+    trunk, heads = _save_classifier(fx, clf, names)
+    for i, l in enumerate(trunk):
+        fx[f"trunk_gw{i}"] = l.weight.grad.numpy().copy()
+        fx[f"trunk_gb{i}"] = l.bias.grad.numpy().copy()
+    for i, l in enumerate(heads):
+        fx[f"head_gw{i}"] = l.weight.grad.numpy().copy()
+        fx[f"head_gb{i}"] = l.bias.grad.numpy().copy()
+    for i, k in enumerate(O.PARAM_KEYS):
+        gr = dict(mod.model.named_parameters())[k].grad
+        fx[f"gck/{k}"] = checksum(gr)
+        if gr.dim() == 1:
+            fx[f"g/{k}"] = gr.numpy().copy()
+        else:
+            idx = sample_idx(gr.numel(), 7 + i)
+            fx[f"gi/{k}"] = idx
+            fx[f"g/{k}"] = gr.reshape(-1)[idx].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"{name}: total={fx['total']:.6f}")
+
+
 def make_label_maps(name):
     # tables of utils.py:82-136, read by executing those three pure functions out of the file text
     # (ps_vae/utils.py itself cannot import here: it needs pytorch_lightning + torchvision)
@@ -361,6 +468,16 @@ if __name__ == "__main__":
     make_decode_case("decode_d256_z64_n33_norm", 256, 64, 33, 0, True)
     make_langevin_case("langevin_d256_z64_n8_t5", 256, 64, 8, 5, 1, 0.05, 1.0, 2)
     make_langevin_case("langevin_d256_z64_n8_t5_lin", 256, 64, 8, 5, 2, 0.1, 0.5, 1)
+    make_langevin_general_case("langevin_ml_tanh_d256_z64_n8_t5", 256, 64, 8, 5, {"gender": 3, "age": 3},
+                               {"gender": 1, "age": 2}, 2, 128, "tanh", 0.05, 1.0)
+    make_langevin_general_case("langevin_ml_lin_d256_z64_n8_t5", 256, 64, 8, 5, {"gender": 3, "accent": 5, "age": 4},
+                               {"age": 3, "gender": 0}, 1, 128, "relu", 0.1, 0.5)   # (a label the target does not name)
+    make_langevin_general_case("langevin_onelogit_d256_z64_n8_t5", 256, 64, 8, 5, 1, 1, 2, 128, "relu", 0.05, 1.0)
+    make_langevin_general_case("langevin_c20_leaky_d256_z32_n8_t5", 256, 32, 8, 5, 20, 13, 2, 64, "leaky_relu", 0.08, 0.7)
+    make_langevin_general_case("langevin_sigmoid_d256_z64_n8_t5", 256, 64, 8, 5, 3, 2, 2, 128, "sigmoid", 0.05, 1.0)
+    make_multilabel_step_case("mlstep_d256_z64_b24_tanh", 256, 64, 24, {"gender": 3, "age": 3}, 2, 128, "tanh", 0.3)
+    make_multilabel_step_case("mlstep_d256_z64_b19_lin", 256, 64, 19, {"gender": 3, "age": 4, "accent": 5}, 1, 128, "relu",
+                              1.0, beta=0.5)
     make_label_maps("label_maps")
     make_classifier_step_case("clfstep_d256_z64_b24_h128", 256, 64, 24, 2, 128, 0.3)
     make_classifier_step_case("clfstep_d256_z64_b19_lin", 256, 64, 19, 1, 128, 1.0, beta=0.5)

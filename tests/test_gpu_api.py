@@ -818,3 +818,115 @@ def test_training_step_graph_path_steps_aside_when_its_buffers_are_still_in_use(
     l.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="gradients are gone"):
         l.backward()
+
+
+# ---- the general LatentClassifier head on HIP: several labels, one-logit head, non-ReLU trunks, up to 32 classes ----------
+def _our_general_classifier(fx, Z):
+    """pseudo_speaker_vae_amd's LatentClassifier in the fixture's configuration, with the fixture's weights"""
+    from ps_vae.latent_classifier import LatentClassifier
+    names, sizes = [str(v) for v in fx["names"]], [int(v) for v in fx["sizes"]]
+    multi = names != ["-"]
+    nl = int(fx["num_layers"])
+    clf = LatentClassifier(Z, dict(zip(names, sizes)) if multi else sizes[0], num_layers=nl, hidden_dim=int(fx["hidden"]),
+                           activation=str(fx["activation"]))
+    lins = [l for l in clf.layers if isinstance(l, torch.nn.Linear)]
+    trunk = lins if multi else lins[:-1]
+    heads = [clf.output_layers[k] for k in names] if multi else [lins[-1]]
+    with torch.no_grad():
+        for i, l in enumerate(trunk):
+            l.weight.copy_(torch.from_numpy(fx[f"trunk_w{i}"])); l.bias.copy_(torch.from_numpy(fx[f"trunk_b{i}"]))
+        for i, l in enumerate(heads):
+            l.weight.copy_(torch.from_numpy(fx[f"head_w{i}"])); l.bias.copy_(torch.from_numpy(fx[f"head_b{i}"]))
+    return clf, trunk, heads, names, multi
+
+
+@pytest.mark.parametrize("name", ["langevin_ml_tanh_d256_z64_n8_t5", "langevin_ml_lin_d256_z64_n8_t5",
+                                  "langevin_onelogit_d256_z64_n8_t5", "langevin_c20_leaky_d256_z32_n8_t5",
+                                  "langevin_sigmoid_d256_z64_n8_t5"])
+def test_general_langevin_matches_reference_golden(name, monkeypatch):
+    """conditional_synthesis on the general fused kernel (psvae_langevin_heads_f32: one launch for the whole chain) against
+    histories the REFERENCE's conditional_synthesis produced with the reference's LatentClassifier: dict targets over
+    several labels, a linear multi-label head, the single one-logit head (N-fold prior, as the reference computes it),
+    20 classes behind leaky-ReLU, a sigmoid trunk"""
+    from pseudo_speaker_vae_amd import sampling
+    from ps_vae.lightning import PseudoSpeakerVAE
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    D, Z = int(fx["D"]), int(fx["Z"])
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z))
+    mod.model.load_state_dict(O.init_params(D, Z, int(fx["pseed"])))
+    mod.classifier, _, _, names, multi = _our_general_classifier(fx, Z)
+    mod = mod.to(DEV)
+    target = ({str(k): int(v) for k, v in zip(fx["target_names"], fx["target_vals"])} if multi else int(fx["target_vals"][0]))
+    calls = []
+    orig = sampling.langevin_general
+    monkeypatch.setattr(sampling, "langevin_general", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    xh, hist = sampling.conditional_synthesis(mod, int(fx["N"]), target, float(fx["step_size"]), int(fx["steps"]),
+                                              float(fx["noise_weight"]), return_history=True, device=DEV,
+                                              z0=torch.from_numpy(fx["z0"]), noises=torch.from_numpy(fx["noises"]))
+    assert calls == [1], "the general fused kernel did not serve this head"
+    assert_close(np.stack(hist), fx["hist"], REL_TOL, "langevin history")
+    assert_close(xh, fx["x_hat"], REL_TOL, "decoded samples")
+
+
+@pytest.mark.parametrize("name", ["mlstep_d256_z64_b24_tanh", "mlstep_d256_z64_b19_lin"])
+def test_multilabel_training_step_matches_reference_golden(name):
+    """training_step with a multi-label LatentClassifier on the general fused cross-entropy step
+    (psvae_classifier_heads_ce_f32) against the fixture from the reference's own training_step + backward
+    (lightning.py:85-95: mean of the labels' cross entropies; the labels' RUNNING sums logged)"""
+    from helpers import check_grads_against_fixture
+    from pseudo_speaker_vae_amd.model import VAEModel
+    from ps_vae.lightning import PseudoSpeakerVAE
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    D, Z, B = int(fx["D"]), int(fx["Z"]), int(fx["B"])
+    names, sizes = [str(v) for v in fx["names"]], [int(v) for v in fx["sizes"]]
+    mod = PseudoSpeakerVAE(model=dict(input_dim=D, latent_dim=Z), kl_loss_weight=float(fx["beta"]),
+                           classifier=dict(input_dim=Z, num_classes=dict(zip(names, sizes)), num_layers=int(fx["num_layers"]),
+                                           hidden_dim=int(fx["hidden"]), activation=str(fx["activation"])),
+                           classifier_loss_weight=float(fx["cw"]))
+    assert mod.multilabel
+    mod.model.load_state_dict(O.init_params(D, Z, int(fx["pseed"])))
+    mod.classifier, trunk, heads, _, _ = _our_general_classifier(fx, Z)
+    mod = mod.to(DEV)
+    eps = torch.from_numpy(fx["eps"]).to(DEV)
+    mod.model.forward = lambda x: VAEModel.forward(mod.model, x, eps=eps)     # the fixture's epsilon
+    y = {k: torch.from_numpy(fx[f"y_{k}"]).to(DEV) for k in names}
+    out = mod.training_step((torch.from_numpy(fx["x"]).to(DEV), y), 0)
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(fx["total"])) <= REL_TOL * max(1.0, abs(float(fx["total"])))
+    for k in names:
+        assert abs(float(mod.logged[f"train_classifier_loss_{k}"]) - float(fx[f"logged_loss_{k}"])) <= REL_TOL * max(1.0, float(fx[f"logged_loss_{k}"]))
+        assert abs(float(mod.logged[f"train_classifier_acc_{k}"]) - float(fx[f"logged_acc_{k}"])) < 1e-6
+    check_grads_against_fixture({k: t.grad for k, t in zip(O.PARAM_KEYS, mod.model.ordered_params())}, fx)
+    for i, l in enumerate(trunk):
+        assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"trunk_gw{i}"]), REL_TOL, f"trunk dW{i}")
+        assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"trunk_gb{i}"]), REL_TOL, f"trunk db{i}")
+    for i, l in enumerate(heads):
+        assert_close(l.weight.grad.cpu(), torch.from_numpy(fx[f"head_gw{i}"]), REL_TOL, f"head {names[i]} dW")
+        assert_close(l.bias.grad.cpu(), torch.from_numpy(fx[f"head_gb{i}"]), REL_TOL, f"head {names[i]} db")
+
+
+@pytest.mark.parametrize("act,C,hidden,Z,B", [("sigmoid", 32, 128, 128, 300), ("leaky_relu", 5, 16, 16, 77), ("tanh", 3, 0, 64, 40)])
+def test_general_single_label_cross_entropy_step_matches_oracle(act, C, hidden, Z, B):
+    """the general fused CE step on single-label heads the tuned kernel does not cover (non-ReLU trunk, 32 classes, a linear
+    head routed through it): loss, hits, d/dz and every parameter gradient against the oracle's CPU autograd"""
+    from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
+    torch.manual_seed(C + B)
+    clf = LatentClassifier(Z, C, num_layers=2 if hidden else 1, hidden_dim=max(hidden, 1), activation=act).to(DEV)
+    with torch.no_grad():
+        for q in clf.parameters():
+            q.mul_(3.0)
+    z = torch.randn(B, Z, device=DEV, requires_grad=True)
+    y = torch.randint(0, C, (B,), device=DEV)
+    loss, hits, per = clf.cross_entropy_heads_step(z, y)
+    (loss * 0.7).backward()
+    lins = [l for l in clf.layers if isinstance(l, torch.nn.Linear)]
+    cpu = lambda l: (l.weight.detach().cpu(), l.bias.detach().cpu())
+    ol, operl, ohits, ogz, otg, ohg = O.classifier_heads_ce([cpu(l) for l in lins[:-1]], [cpu(lins[-1])], z.detach().cpu(),
+                                                            [y.cpu()], act)
+    assert abs(float(loss) - float(ol)) <= REL_TOL * max(1.0, float(ol)) and int(hits[None]) == ohits[0]
+    assert abs(float(per[None]) - float(operl[0])) <= REL_TOL * max(1.0, float(ol))
+    assert_close(z.grad.cpu(), 0.7 * ogz, REL_TOL, "d loss / d z")
+    for l, (gW, gb) in zip(lins[:-1], otg):
+        assert_close(l.weight.grad.cpu(), 0.7 * gW, REL_TOL, "trunk dW"); assert_close(l.bias.grad.cpu(), 0.7 * gb, REL_TOL, "trunk db")
+    assert_close(lins[-1].weight.grad.cpu(), 0.7 * ohg[0][0], REL_TOL, "head dW")
+    assert_close(lins[-1].bias.grad.cpu(), 0.7 * ohg[0][1], REL_TOL, "head db")

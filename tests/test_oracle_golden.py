@@ -202,3 +202,70 @@ def test_embedding_classifier_head_alone_matches_reference(name):
     for i, (gW, gb) in enumerate(pg):
         assert_close(gW, torch.from_numpy(fx[f"head_gw{i}"]), 2e-5, f"dW{i}")
         assert_close(gb, torch.from_numpy(fx[f"head_gb{i}"]), 2e-5, f"db{i}")
+
+
+# ---- the general LatentClassifier head: several labels, one-logit head, non-ReLU trunks (csrc/heads_general.hip's checker) ----
+GEN_LANGEVIN = ["langevin_ml_tanh_d256_z64_n8_t5", "langevin_ml_lin_d256_z64_n8_t5", "langevin_onelogit_d256_z64_n8_t5",
+                "langevin_c20_leaky_d256_z32_n8_t5", "langevin_sigmoid_d256_z64_n8_t5"]
+
+
+def general_head_from_fixture(fx):
+    """(trunk, all heads, names, sizes, activation) of a fixture written by make_golden._save_classifier"""
+    trunk = [(torch.from_numpy(fx[f"trunk_w{i}"]), torch.from_numpy(fx[f"trunk_b{i}"])) for i in range(int(fx["n_trunk"]))]
+    sizes = [int(v) for v in fx["sizes"]]
+    heads = [(torch.from_numpy(fx[f"head_w{i}"]), torch.from_numpy(fx[f"head_b{i}"])) for i in range(len(sizes))]
+    names = [str(v) for v in fx["names"]]
+    return trunk, heads, names, sizes, str(fx["activation"])
+
+
+def targeted_heads(fx):
+    trunk, heads, names, sizes, act = general_head_from_fixture(fx)
+    if int(fx["multi"]):
+        tn = [str(v) for v in fx["target_names"]]
+        pick = [names.index(k) for k in tn]
+    else:
+        pick = [0]
+    targets = [int(v) for v in fx["target_vals"]]
+    one_logit = (not int(fx["multi"])) and sizes[0] == 1
+    return trunk, [heads[i] for i in pick], targets, act, (float(fx["N"]) if one_logit else 1.0)
+
+
+@pytest.mark.parametrize("name", GEN_LANGEVIN)
+def test_general_langevin_oracle_matches_reference_histories(name):
+    """oracle.langevin_heads against the reference's own conditional_synthesis (inference.py:29-110, unmodified) driving the
+    reference's LatentClassifier: dict targets over several labels (one label left out of the target), a linear multi-label
+    head, the single one-logit head with its N-fold prior, 20 classes behind leaky-ReLU, a sigmoid trunk"""
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    trunk, heads, targets, act, prior_scale = targeted_heads(fx)
+    z, hist = O.langevin_heads(trunk, heads, targets, act, torch.from_numpy(fx["z0"]), torch.from_numpy(fx["noises"]),
+                               float(fx["step_size"]), float(fx["noise_weight"]), prior_scale)
+    assert_close(torch.stack(hist), torch.from_numpy(fx["hist"]), 2e-5, "history")
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    assert_close(O.decode(p, z), torch.from_numpy(fx["x_hat"]), 2e-5, "decoded samples")
+
+
+@pytest.mark.parametrize("name", ["mlstep_d256_z64_b24_tanh", "mlstep_d256_z64_b19_lin"])
+def test_multilabel_training_step_oracle_matches_reference(name):
+    """oracle.train_step_with_label_heads against the reference's own training_step + backward on its multi-label branch
+    (lightning.py:85-95): total / recon / kl, the labels' logged running losses and accuracies, all 18 VAE gradients, the
+    trunk's and every label head's"""
+    fx = load(os.path.join(GOLDEN, name + ".npz"))
+    p = O.init_params(int(fx["D"]), int(fx["Z"]), int(fx["pseed"]))
+    trunk, heads, names, sizes, act = general_head_from_fixture(fx)
+    x, eps = torch.from_numpy(fx["x"]), torch.from_numpy(fx["eps"])
+    ys = [torch.from_numpy(fx[f"y_{k}"]) for k in names]
+    losses, grads, tg, hg = O.train_step_with_label_heads(p, trunk, heads, x, ys, eps, float(fx["beta"]), float(fx["cw"]), act)
+    for k in ("total", "recon", "kl"):
+        assert abs(float(losses[k]) - float(fx[k])) <= 2e-5 * max(1.0, abs(float(fx[k]))), k
+    running = 0.0
+    for k, q, h in zip(names, losses["per_label"], losses["hits"]):
+        running += float(q)
+        assert abs(running - float(fx[f"logged_loss_{k}"])) <= 2e-5 * max(1.0, running), k   # the running sum (lightning.py:93)
+        assert abs(h / x.shape[0] - float(fx[f"logged_acc_{k}"])) < 1e-6, k
+    check_grads_against_fixture(grads, fx, tol=2e-5)
+    for i, (gW, gb) in enumerate(tg):
+        assert_close(gW, torch.from_numpy(fx[f"trunk_gw{i}"]), 2e-5, f"trunk dW{i}")
+        assert_close(gb, torch.from_numpy(fx[f"trunk_gb{i}"]), 2e-5, f"trunk db{i}")
+    for i, (gW, gb) in enumerate(hg):
+        assert_close(gW, torch.from_numpy(fx[f"head_gw{i}"]), 2e-5, f"head {names[i]} dW")
+        assert_close(gb, torch.from_numpy(fx[f"head_gb{i}"]), 2e-5, f"head {names[i]} db")
