@@ -461,18 +461,24 @@ def prewarm(step, args, rk: Rank):
         torch.cuda.synchronize(rk.dev)
 
 
-def committed_traffic(D, Z, B, dtype, plan):
+def committed_traffic(D, Z, B, dtype, plan, cond=False):
     """HBM-side bytes per step from the committed rocprofv3 PMC passes -- reported with its provenance, and only when
     the committed passes were taken on this shape; never presented as measured in this run"""
-    for name in ("r02_cfg2_pmc.json", "r01_cfg2_pmc.json"):
+    if (D, Z, B, dtype, cond) == (256, 64, 4096, "bf16", True):
+        names = ("r03_cfg3_pmc.json",)
+    elif (D, Z, B, dtype, cond) == (256, 64, 1024, "f32", False):
+        names = ("r03_cfg2_pmc.json", "r02_cfg2_pmc.json", "r01_cfg2_pmc.json")
+    else:
+        return None, None
+    for name in names:
         path = os.path.join(REPO, "profiles", name)
-        if (D, Z, B, dtype) == (256, 64, 1024, "f32") and os.path.exists(path):
+        if os.path.exists(path):
             try:
                 rec = json.load(open(path))
             except (OSError, ValueError):
                 continue
             same_plan = rec.get("launch_plan") in (None, plan)
-            return rec.get("hbm_bytes_per_step"), f"profiles/{name} (separate rocprofv3 --pmc passes of `python bench.py`" \
+            return rec.get("hbm_bytes_per_step"), f"profiles/{name} (separate rocprofv3 --pmc passes of `python bench.py ...`" \
                 + ("" if same_plan else "; taken under a DIFFERENT launch plan than this run's") + ")"
     return None, None
 
@@ -647,7 +653,7 @@ def run_rank(args) -> int:
     ranks_seen = rk.ranks_seen()
 
     if rank == 0:
-        traffic, traffic_source = committed_traffic(D, Z, B, args.dtype, plan)
+        traffic, traffic_source = committed_traffic(D, Z, B, args.dtype, plan, args.cond)
         fpe = flop_per_embedding(D, Z) + (2 * 3 * 2 * 6 * H if args.cond else 0)  # +6 one-hot columns x3, fwd+wgrad
         peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         step_s_dev = dev_ms / 1e3 / args.steps

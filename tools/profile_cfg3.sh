@@ -42,7 +42,16 @@ for pos, name in enumerate(order):
     tf += f; tw += w; tm += m
     print(f"| `{name}` | {f:.1f} | {w:.1f} | {m:.1f} | {h:.2f} |")
 print(f"| **step** | **{tf:.1f}** | **{tw:.1f}** | **{tm:.1f}** | |")
+import json
+json.dump({"hbm_bytes_per_step": int((tf + tw) * 1024 * 1024), "fetch_x2_mb": round(tf, 1), "write_mb": round(tw, 1),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --dtype bf16 --cond --batch 4096 --mode eager`, all launches of one step",
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted: L2-fill traffic, an upper bound on HBM bytes"},
+          open(raw.replace("/tmp/psvae_prof_cfg3", "gpurun_out/prof_cfg3") + "/pmc.json", "w"), indent=1)
 print("\n(FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 reports half of wide coalesced reads; Infinity-Cache hits are counted, so the"
       " figure is L2-fill traffic, an upper bound on HBM bytes.)")
 PY
-cat "$OUT/pmc.md"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/trace" -- python3 bench.py --dtype bf16 --cond --batch 4096 --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log"
+find "$RAW/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+python3 tools/parse_trace.py "$RAW/trace" 100 > "$OUT/timeline.txt"
+python3 bench.py --dtype bf16 --cond --batch 4096 > "$OUT/bench.json" 2> "$OUT/bench.log"
+cat "$OUT/pmc.md" "$OUT/timeline.txt"; tail -1 "$OUT/bench.json"

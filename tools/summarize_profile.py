@@ -19,7 +19,7 @@ st = glob.glob(raw + "/trace/**/*_kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
     steps = json.loads(open(out + "/bench_under_trace.json").read().strip().splitlines()[-1])
-    print("## `rocprofv3 --kernel-trace --stats -- python3 bench.py` (graph mode)\n")
+    print("## `rocprofv3 --kernel-trace --stats -- python3 bench.py` (launch form: " + str(steps.get("config", {}).get("launch")) + "; the run also holds the calibration's launches of the other form: same kernels)\n")
     print("| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|")
     tot = 0
     for r in rows:
