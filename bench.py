@@ -682,6 +682,10 @@ def run_rank(args) -> int:
                        "batch_source": ("each step's rows gathered on the device from a shuffled packed table "
                                         "(psvae_gather_rows_f32, inside the timed step)") if args.gather else
                                        "one static batch resident in HBM (batch assembly is outside the timed step; --gather times it)",
+                       "weight_copies": ("k-major fp32 copies kept current by the optimizer step (outside fwd+bwd)" if args.dtype == "f32" else
+                                          "bf16 packs rebuilt inside every pass (PSVAE_BF16_PACK_IN_STEP=1)" if getattr(eng, "_pack_in_step", False) else
+                                          "bf16 packs kept current by the optimizer step (outside fwd+bwd; PSVAE_BF16_PACK_IN_STEP=1 "
+                                          "rebuilds them inside every pass)"),
                        "launch_plan": plan, "launches_per_step": eng.launches_per_step(),
                        "prewarm_ms": args.prewarm_ms, "calibration": calibrated},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak,

@@ -33,6 +33,9 @@ extern "C" {
 /* flags */
 #define PSVAE_NORMALIZE_DECODER 1u /* model.py:60-61, 67-68 */
 #define PSVAE_COS_LOSS 2u          /* lightning.py:110-111 */
+/* psvae_*_bf16 passes only: the bf16 weight packs in `scratch` are current (psvae_pack_params_bf16 ran after the last
+ * parameter update), do not rebuild them in this pass */
+#define PSVAE_BF16_PACKS_CURRENT 0x100u
 
 /* backward phases (psvae_backward_f32 `phases`): decoder grads are complete after phase 1, so a
  * data-parallel caller can start their all-reduce while phase 2 (both encoders) still runs */
@@ -199,6 +202,12 @@ int psvae_set_plan(const psvae_dims* dims, const char* text);
  * available on the row-chain shapes (PSVAE_ERR_SHAPE elsewhere): the decoder chain leaves the raw output and one row kernel
  * normalises, takes the loss term and the gradient w.r.t. the raw output. */
 size_t psvae_bf16_scratch_bytes(const psvae_dims* dims);
+/* The bf16 working copies of the 9 weight matrices, in the layouts the row chains read (16 packs in `scratch`), from the
+ * fp32 master weights: one launch.  A pass rebuilds them itself unless it is told they are current
+ * (flags | PSVAE_BF16_PACKS_CURRENT): the mixed-precision arrangement in which the optimizer step, which changes the
+ * master weights (lightning.py:205, torch.optim.Adam), also refreshes the working copies -- as the fp32 step's k-major
+ * copies are (psvae_step_opts::params_kmajor).  No-op (PSVAE_OK) on shapes that take a launch per layer. */
+int psvae_pack_params_bf16(const psvae_dims* dims, const psvae_params* params, void* scratch, void* stream);
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params,
                           const psvae_cond* cond /* nullable */, const float* eps_in /* nullable */,
                           uint64_t seed, uint64_t offset, uint64_t* rng_state /* nullable */, float* eps_out,

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 REPO = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libpsvae_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "elementwise.hip", "bottleneck.hip", "langevin.hip", "decode_fused.hip", "chain_bf16.hip", "classifier.hip", "heads_general.hip", "ipc_allreduce.hip", "psvae_api.hip",
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "elementwise.hip", "bottleneck.hip", "langevin.hip", "decode_fused.hip", "chain_bf16.hip", "classifier.hip", "heads_general.hip", "ipc_allreduce.hip", "psvae_api.hip",
            "psvae_api_bf16.hip"]
 ARCH = "gfx950"
 

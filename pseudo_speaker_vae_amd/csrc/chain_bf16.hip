@@ -134,7 +134,8 @@ hipError_t launch_chain_pack(const float* const* W, u16* const* Wp, const int* O
     ChainPackArgs a{};
     for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.Wp[k] = Wp[k]; a.OUT[k] = OUT[k]; a.IN[k] = IN[k]; a.T[k] = T ? T[k] : 0; }
     a.n = n; a.x = x; a.xb = xb; a.nx = nx; a.gender = gender; a.age = age; a.oh = oh; a.B = B;
-    hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n + 1 + (oh ? 1 : 0)), dim3(256), 0, s, a);
+    // (x == nullptr: weights only -- the training pass's encoder chain writes xb and the one-hot rows itself)
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(128, n + (x ? 1 + (oh ? 1 : 0) : 0)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -218,13 +219,14 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             }
     }
     int tg[RG], ta[RG];                                  // table rows of this lane's rows (one per row group)
+    int lg[RG], la[RG];                                  // (the labels themselves, for the one-hot rows below)
     if (has_tab) {
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
             long row = tile * TR + 16 * g + r;
             row = row < a.B ? row : a.B - 1;
-            tg[g] = a.gender[row];
-            ta[g] = a.age[row];
+            lg[g] = tg[g] = a.gender[row];
+            la[g] = ta[g] = a.age[row];
         }
     }
     // input rows: the tile's RG x KB0 (row group, k step) pieces are dealt over the four wavefronts.  The decoder chain of
@@ -309,7 +311,36 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
-        if (pc < RG * KB0) *reinterpret_cast<bf16x8*>(act + (kb * RG + g) * 1024 + lane * 16) = pack8<false>(vin[i][0], vin[i][1]);
+        if (pc < RG * KB0) {
+            const bf16x8 pk = pack8<false>(vin[i][0], vin[i][1]);
+            *reinterpret_cast<bf16x8*>(act + (kb * RG + g) * 1024 + lane * 16) = pk;
+            if constexpr (!RECON) {
+                // the row-major bf16 copy of the input rows the weight gradients read (was a rider of the pack launch)
+                const long row = tile * TR + 16 * g + r;
+                if (a.xb_out && row < a.B) {
+                    u16* xp = a.xb_out + (size_t)row * a.K0 + 32 * kb + 4 * q;
+                    *reinterpret_cast<bf16x4*>(xp) = bf16x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<bf16x4*>(xp + 16) = bf16x4{pk[4], pk[5], pk[6], pk[7]};
+                }
+            }
+        }
+    }
+    if constexpr (!RECON) {
+        if (a.oh_out && has_tab && wave == 0 && q == 0) {  // one-hot label rows [B][8] (model.py:71-76: the concatenated labels)
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                const long row = tile * TR + 16 * g + r;
+                if (row < a.B) {
+                    bf16x8 oh = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        oh[c] = (lg[g] == c) ? (short)0x3F80 : (short)0;
+                        oh[3 + c] = (la[g] == c) ? (short)0x3F80 : (short)0;
+                    }
+                    *reinterpret_cast<bf16x8*>(a.oh_out + (size_t)row * 8) = oh;
+                }
+            }
+        }
     }
     __syncthreads();
     if (rep && tid == 0) a.kl_partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);

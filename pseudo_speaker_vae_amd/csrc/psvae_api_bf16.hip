@@ -109,9 +109,32 @@ inline GemmDescBf bdesc(int M, int N, int K, const u16* A, int lda, const u16* B
 }
 inline void addb(GemmBatchBf& b, const GemmDescBf& d) { b.d[b.n++] = d; }
 
+// the 16 weight packs of the row chains (9 plain for the forward chains, 7 transposed for the gradient chains): one launch
+inline hipError_t chain_pack_weights(const BfScratch& sc, const float* const* P, const int* wo, const int* wi, hipStream_t s) {
+    const float* Wsrc[16]; u16* Wdst[16]; int po[16], pi[16], pt[16]; int np = 0;
+    for (int k = 0; k < 9; ++k) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.Wc[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 0; }
+    for (int k = 0; k < 9; ++k)
+        if (k != 0 && k != 3) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.WcT[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 1; }
+    return launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, s);
+}
+
 }  // namespace
 
 extern "C" {
+
+int psvae_pack_params_bf16(const psvae_dims* dims, const psvae_params* params, void* scratch, void* stream) {
+    if (!dims || !params || !scratch) return PSVAE_ERR_NULL;
+    if (dims->B <= 0 || dims->D <= 0 || dims->Z <= 0 || (dims->D & 31) || (dims->Z & 31)) return PSVAE_ERR_SHAPE;
+    for (int k = 0; k < 9; ++k)
+        if (!params->p[2 * k]) return PSVAE_ERR_NULL;
+    const int B = (int)dims->B, D = (int)dims->D, Z = (int)dims->Z;
+    if (!(chain_fwd_ok(B, D, Z) && chain_fwd_ok(B, Z, D))) return PSVAE_OK;  // per-layer shapes cast inside every pass
+    BfScratch sc = carve_bf(scratch, B, D, Z);
+    int wo[9], wi[9];
+    weight_dims(D, Z, wo, wi);
+    RET_IF(chain_pack_weights(sc, params->p, wo, wi, (hipStream_t)stream));
+    return PSVAE_OK;
+}
 
 size_t psvae_bf16_scratch_bytes(const psvae_dims* dims) {
     if (!dims || dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return 0;
@@ -129,7 +152,8 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     t_bf_launches = 0;
 #define LAUNCH(e) do { RET_IF(e); ++t_bf_launches; } while (0)
     const bool normalize = flags & PSVAE_NORMALIZE_DECODER, cos_loss = flags & PSVAE_COS_LOSS;
-    if (flags & ~(uint32_t)(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS)) return PSVAE_ERR_ARG;
+    const bool packs_current = flags & PSVAE_BF16_PACKS_CURRENT;  // (row-chain path: skip the weight-pack launch)
+    if (flags & ~(uint32_t)(PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS | PSVAE_BF16_PACKS_CURRENT)) return PSVAE_ERR_ARG;
     if (!dims || !x || !params || !x_hat || !mu || !logvar || !scratch || !eps_out || !z_out) return PSVAE_ERR_NULL;
     if (bwd && (!grads || !loss3)) return PSVAE_ERR_NULL;
     if (dims->B <= 0 || dims->D <= 0 || dims->Z <= 0) return PSVAE_ERR_SHAPE;
@@ -162,7 +186,7 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
     if ((normalize || cos_loss) && !chain) return PSVAE_ERR_SHAPE;  // the loss variants exist on the row-chain path only
     if (fwd) {
     if (chain) {  // (the chains read fp32 x and their own weight packs; x -> bf16 and the one-hot matrix, which only the weight
-                  //  gradients read, ride the pack launch below)
+                  //  gradients read, are written by the first encoder chain as the rows pass through it)
     } else {  // fp32 master weights -> bf16 in both layouts (one launch, 9 tensors); x likewise
         const float* src[10]; u16* dst[10]; u16* dstT[10]; int R[10], C[10], ld[10], ldt[10];
         for (int k = 0; k < 9; ++k) {
@@ -175,13 +199,9 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
                                      has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B));
     }
     if (chain) {
-        // one launch packs W for the forward chains and W^T (all but the two input layers) for the backward chains
-        const float* Wsrc[16]; u16* Wdst[16]; int po[16], pi[16], pt[16]; int np = 0;
-        for (int k = 0; k < 9; ++k) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.Wc[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 0; }
-        for (int k = 0; k < 9; ++k)
-            if (k != 0 && k != 3) { Wsrc[np] = P[2 * k]; Wdst[np] = sc.WcT[k]; po[np] = wo[k]; pi[np] = wi[k]; pt[np++] = 1; }
-        LAUNCH(launch_chain_pack(Wsrc, Wdst, po, pi, pt, np, x, sc.xb, (long)B * D, has_cond ? cond->gender : nullptr,
-                                 has_cond ? cond->age : nullptr, has_cond ? sc.oh : nullptr, B, s));
+        // one launch packs W for the forward chains and W^T (all but the two input layers) for the backward chains -- unless the
+        // caller keeps the packs in `scratch` current itself (psvae_pack_params_bf16 after every parameter update)
+        if (!packs_current) LAUNCH(chain_pack_weights(sc, P, wo, wi, s));
         auto mlp = [&](const float* in, int K0, int NOUT, int w0, u16* s0, u16* s1, float* out, const float* ctab) {
             ChainArgs c{};
             c.in = in; c.B = B; c.K0 = K0; c.NOUT = NOUT;
@@ -193,6 +213,8 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         {
             ChainBatch cb{};
             cb.c[0] = mlp(x, D, Z, 0, sc.h1m, sc.h2m, mu, has_cond ? cond->tab[0] : nullptr);
+            cb.c[0].xb_out = sc.xb;  // (the weight gradients' operands: x in bf16, the one-hot label rows)
+            cb.c[0].oh_out = has_cond ? sc.oh : nullptr;
             cb.c[1] = mlp(x, D, Z, 3, sc.h1s, sc.h2s, logvar, has_cond ? cond->tab[1] : nullptr);
             cb.n = 2;
             LAUNCH(launch_chain_fwd_bf16(cb, s));
@@ -349,22 +371,25 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
         }
         {
             GemmBatchBf b{};
+            // (order = the launch's work list inside one batch slice: problems that read the same array are neighbours, so
+            // that they run under the same L2 -- a table gradient next to the layer whose dY it shares, the two first
+            // encoder layers, which share x: wgrad_bf16.hip)
             addb(b, wgrad(sc.gy, D, D, sc.d2, H, G[16], G[17], sc.slab_w[8], sc.slab_b[8]));
             addb(b, wgrad(sc.dd2, H, H, sc.d1, H, G[14], G[15], sc.slab_w[7], sc.slab_b[7]));
             addb(b, wgrad(sc.dd1, H, H, sc.zb, Z, G[12], G[13], sc.slab_w[6], sc.slab_b[6]));
+            if (has_cond) addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dd1, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));
             addb(b, wgrad(sc.gmu, Z, Z, sc.h2m, H, G[4], G[5], sc.slab_w[2], sc.slab_b[2]));
-            addb(b, wgrad(sc.glv, Z, Z, sc.h2s, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
             addb(b, wgrad(sc.dh2m, H, H, sc.h1m, H, G[2], G[3], sc.slab_w[1], sc.slab_b[1]));
+            addb(b, wgrad(sc.glv, Z, Z, sc.h2s, H, G[10], G[11], sc.slab_w[5], sc.slab_b[5]));
             addb(b, wgrad(sc.dh2s, H, H, sc.h1s, H, G[8], G[9], sc.slab_w[4], sc.slab_b[4]));
             addb(b, wgrad(sc.dh1m, H, H, sc.xb, D, G[0], G[1], sc.slab_w[0], sc.slab_b[0]));
+            if (has_cond) addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1m, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
             addb(b, wgrad(sc.dh1s, H, H, sc.xb, D, G[6], G[7], sc.slab_w[3], sc.slab_b[3]));
-            if (has_cond) {
-                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dd1, H, cond->gtab[2], nullptr, sc.slab_t[2], nullptr));
-                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1m, H, cond->gtab[0], nullptr, sc.slab_t[0], nullptr));
-                addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
-            }
+            if (has_cond) addb(b, wgrad(sc.oh, PSVAE_COND_DIM, 8, sc.dh1s, H, cond->gtab[1], nullptr, sc.slab_t[1], nullptr));
             b.force_staged = 1;
-            LAUNCH(launch_gemm_batch_bf16(b, s));
+            static const bool old_wgrad = getenv("PSVAE_WGRAD_V1") != nullptr && atoi(getenv("PSVAE_WGRAD_V1")) != 0;
+            if (old_wgrad) LAUNCH(launch_gemm_batch_bf16(b, s));  // round 2's register-staged kernel (A/B runs)
+            else LAUNCH(launch_wgrad_batch_bf16(b, s));
         }
         if (nred) LAUNCH(launch_slab_reduce(rsrc, rdst, rnum, rS, nred, s));
         return 0;

@@ -164,8 +164,11 @@ struct GemmBatchBf {
     int total_tiles;
     int force_staged;  // host-side: 1 = launch with the LDS-staged 128x128 kernel whatever the tile count
     int xcd_remap;     // 1: XCD-aware tile order inside each problem (set by the launcher)
+    int tiles_per_slice;  // wgrad_bf16.hip: tiles of all problems of ONE batch slice (its work list is slice-major)
 };
 hipError_t launch_gemm_batch_bf16(GemmBatchBf& b, hipStream_t stream);
+// wgrad_bf16.hip: a batch of tr = 1 problems (weight gradients) on the LDS-DMA pipeline; same descriptors, fp32 out
+hipError_t launch_wgrad_batch_bf16(GemmBatchBf& b, hipStream_t stream);
 hipError_t launch_cast_transpose(const float* const* src, unsigned short* const* dst, unsigned short* const* dstT,
                                  const int* R, const int* C, const int* ld, const int* ldt, int n, hipStream_t s,
                                  const int32_t* gender = nullptr, const int32_t* age = nullptr,
@@ -346,6 +349,10 @@ struct ChainArgs {
     unsigned short* zb;              // [B, K0] bf16
     float* kl_partials;              // [tiles]: sum of 1 + lv - mu^2 - exp(lv)
     int raw_out;                     // 1: only write the raw third-layer output to `out` (the loss variants' row kernel follows)
+    // encoder of a training pass (nullable): the bf16 row-major copy of its input rows [B, K0] and the one-hot label matrix
+    // [B][8] (columns 6, 7 zero) -- the weight-gradient launch's operands, written as the rows pass through
+    unsigned short* xb_out;
+    unsigned short* oh_out;
 };
 struct ChainBatch {
     ChainArgs c[2];

@@ -17,6 +17,7 @@ On one GPU the whole step (forward + ELBO + backward [+ Adam]) is captured into 
 from __future__ import annotations
 
 import math
+import os
 import struct
 from typing import List, Optional
 
@@ -139,7 +140,6 @@ class TrainEngine:
         self.loss3 = self.flat_grads[self.layout.loss_offset:self.layout.loss_offset + 3]
         # bucket 0 = encoders + loss scalars, bucket 1 = decoder (reduced first: its grads are ready first)
         if direct_allreduce is None:  # PSVAE_DDP_DIRECT=1: the one-shot exchange over IPC buffers instead of RCCL's all-reduce
-            import os
             direct_allreduce = os.environ.get("PSVAE_DDP_DIRECT") == "1"
         self.averager = GradAverager(self.flat_grads, [0, self.layout.enc_end, n], process_group, direct=direct_allreduce) \
             if process_group is not None else None
@@ -158,6 +158,11 @@ class TrainEngine:
                                  "row-chain shapes only: batch >= 64, input_dim in {128, 256, 512}, latent_dim in {64, 128}")
             self.ws = ops.Bf16Workspace(batch, input_dim, latent_dim, self.device)
             self.outs = (self.ws.x_hat, self.ws.mu, self.ws.logvar)
+            # bf16 working copies of the weights (the row chains' packs, inside the workspace): made here, refreshed by
+            # optimizer_step -- the step itself does not rebuild them (PSVAE_BF16_PACK_IN_STEP=1: it does, one launch more)
+            self._pack_in_step = os.environ.get("PSVAE_BF16_PACK_IN_STEP", "0") == "1"
+            self._packed_version = None
+            self.refresh_packs()
         else:
             self.ws = ops.Workspace(batch, input_dim, latent_dim, self.device, normalize_decoder)
             self.outs = self.ws.new_outputs()
@@ -192,6 +197,20 @@ class TrainEngine:
         engine's own optimizer keeps them current)"""
         if self.params_t is not None:
             ops.transpose_params(self.ws, self.params, self.params_t)
+
+    def refresh_packs(self):
+        """bf16 engine: re-make the bf16 working copies of the weights from flat_params.  optimizer_step does it; writes
+        to the parameters through torch ops are noticed by their version counter and trigger it before the next step."""
+        if self.dtype == "bf16" and not self._pack_in_step:
+            ops.pack_params_bf16(self.ws, self.params)
+            self._packed_version = self.flat_params._version
+
+    def _packs_flag(self) -> int:
+        if self.dtype != "bf16" or self._pack_in_step:
+            return 0
+        if self.flat_params._version != self._packed_version:  # parameters written by hand since the last pack
+            self.refresh_packs()
+        return _ffi.BF16_PACKS_CURRENT
 
     def _step_kwargs(self):
         return dict(params_kmajor=self.params_t, cond=self._cond, flags=self.flags)
@@ -228,7 +247,7 @@ class TrainEngine:
             raise _ffi.PsvaeError("conditional engine: call set_labels(gender, age) for this batch first")
         if self.dtype == "bf16":
             ops.train_step_bf16(self.ws, x, self.params, self.grads, self.loss3, beta=self.beta, eps=eps,
-                                rng_state=self.rng_state, cond=self._cond, flags=self.flags)
+                                rng_state=self.rng_state, cond=self._cond, flags=self.flags | self._packs_flag())
             if self.averager is not None and not _local_only:
                 self.averager.reduce_all()
                 self.averager.wait()
@@ -309,6 +328,7 @@ class TrainEngine:
             self._write_lr(lr)
         self.step_count += 1
         ops.adam_step_dev(self._adam_layout, self.adam_state, self.betas, self.adam_eps, self.weight_decay)
+        self.refresh_packs()  # (bf16: the working copies follow the master weights; a no-op for fp32)
 
     def adam_steps_done(self) -> int:
         """the device-side step counter (a host sync)"""
@@ -355,7 +375,9 @@ class TrainEngine:
             self.forward_backward(self.static_x, _local_only=True)
             if with_adam:
                 ops.adam_step_dev(self._adam_layout, self.adam_state, self.betas, self.adam_eps, self.weight_decay)
+        self.refresh_packs()  # (bf16: the working copies follow the master weights; a no-op for fp32)
         self._warm(body)
+        self._packs_flag()  # (bf16: repack now, after the warm-up state was restored -- not inside the capture)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             body()
@@ -367,6 +389,7 @@ class TrainEngine:
     def replay(self):
         """one captured step; with a process group: followed by ONE all-reduce of the flat gradient buffer
         (the collective itself stays outside the graph)"""
+        self._packs_flag()  # (bf16: parameters overwritten by hand since the last pack -> repack, outside the graph)
         self._graph.replay()
         if self.averager is not None and not self._collective_in_graph:
             self.averager.reduce_all()
@@ -399,6 +422,7 @@ class TrainEngine:
             self.averager.wait()
 
         self._warm(body, 3)
+        self._packs_flag()  # (bf16: repack now, after the warm-up state was restored -- not inside the capture)
         dist.barrier(group=self.averager.pg)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -421,6 +445,7 @@ class TrainEngine:
             ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3, **kw)
             self._skip_rng()
         self._warm(warm)
+        self._packs_flag()  # (bf16: repack now, after the warm-up state was restored -- not inside the capture)
         self._ga, self._gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._ga):
             ops.train_step(self.ws, self.static_x, self.params, self.grads, self.outs, self.loss3,

@@ -254,7 +254,8 @@ def train_step_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads:
                     beta: float = 1.0, eps: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
                     rng_state: Optional[torch.Tensor] = None, grad_loss: Optional[torch.Tensor] = None, cond=None,
                     flags: int = 0):
-    """one training pass with bf16 MFMA operands (config 3): psvae_train_step_bf16; flags: NORMALIZE_DECODER | COS_LOSS"""
+    """one training pass with bf16 MFMA operands (config 3): psvae_train_step_bf16; flags: NORMALIZE_DECODER | COS_LOSS |
+    BF16_PACKS_CURRENT (the weight packs in ws.scratch are current: pack_params_bf16)"""
     P = _ffi.make_params(params)
     G = _ffi.make_grads(grads)
     _ffi.check(_ffi.lib().psvae_train_step_bf16(
@@ -262,6 +263,14 @@ def train_step_bf16(ws: Bf16Workspace, x, params: Sequence[torch.Tensor], grads:
         _ffi.ptr(eps), seed, offset, _ffi.ptr(rng_state), _ffi.ptr(ws.eps), _ffi.ptr(ws.z), _ffi.ptr(ws.x_hat),
         _ffi.ptr(ws.mu), _ffi.ptr(ws.logvar), beta, _ffi.ptr(grad_loss), C.byref(G), _ffi.ptr(loss3),
         _ffi.ptr(ws.scratch), flags, _ffi.stream_ptr()), "train_step_bf16")
+
+
+def pack_params_bf16(ws: Bf16Workspace, params: Sequence[torch.Tensor]) -> None:
+    """refresh the bf16 working copies of the weights inside ws.scratch (psvae_pack_params_bf16): after every parameter
+    update when the passes run with flags | BF16_PACKS_CURRENT"""
+    P = _ffi.make_params(params)
+    _ffi.check(_ffi.lib().psvae_pack_params_bf16(C.byref(ws.dims), C.byref(P), _ffi.ptr(ws.scratch), _ffi.stream_ptr()),
+               "pack_params_bf16")
 
 
 def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,

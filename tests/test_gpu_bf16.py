@@ -293,3 +293,58 @@ def test_bf16_row_chains_are_deterministic_and_row_local():
         # (each half normalises by its own 2,048 rows and rounds its MSE / KL gradients to bf16 at that scale: the mean of
         #  the shards' gradients equals the full-batch gradient up to those roundings)
         assert_close_bf16(((b0 + b1) / 2).cpu(), a.cpu(), "shard mean " + k)
+
+
+def test_bf16_packs_kept_by_the_optimizer_step_equal_packs_rebuilt_in_the_pass():
+    """PSVAE_BF16_PACKS_CURRENT (include/psvae.h): a pass that is told the bf16 weight packs in its scratch are current
+    skips the pack launch and gives the SAME bits as a pass that rebuilds them; the engine keeps them current across its
+    fused Adam and notices parameters written through torch ops (their version counter)"""
+    from pseudo_speaker_vae_amd import _ffi, ops
+    from pseudo_speaker_vae_amd.engine import TrainEngine
+    D, Z, B = 256, 64, 640
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, D, generator=g).to(DEV)
+    eps = torch.randn(B, Z, generator=g).to(DEV)
+    gender, age = torch.randint(-1, 3, (B,), generator=g), torch.randint(-1, 3, (B,), generator=g)
+    eng = TrainEngine(D, Z, B, device=DEV, seed=4, dtype="bf16", conditional=True, lr=1e-2)
+    eng.set_labels(gender, age)
+
+    def raw_pass():  # the C entry without the flag, on its own workspace: packs rebuilt inside the pass
+        ws = ops.Bf16Workspace(B, D, Z, DEV)
+        grads = [torch.full_like(t, float("nan")) for t in eng.params]
+        gtab = [torch.full_like(t, float("nan")) for t in eng.cond_tabs]
+        c = _ffi.make_cond(list(eng.cond_tabs), gtab, eng.gender, eng.age)
+        loss3 = torch.full((3,), float("nan"), device=DEV)
+        ops.train_step_bf16(ws, x, eng.params, grads, loss3, beta=eng.beta, eps=eps, cond=c)
+        n = ops.last_step_launches_bf16()
+        torch.cuda.synchronize()
+        return grads, gtab, loss3, n
+
+    for it in range(3):
+        eng.forward_backward(x, eps=eps)
+        assert eng.launches_per_step() == 6
+        torch.cuda.synchronize()
+        grads, gtab, loss3, n = raw_pass()
+        assert n == 7
+        for k, a, b in zip(O.PARAM_KEYS, eng.grads, grads):
+            assert torch.equal(a, b), f"iteration {it}: grad {k} differs from the pass that packs for itself"
+        assert torch.equal(eng.loss3, loss3)
+        if it == 0:
+            eng.optimizer_step()               # Adam changes the master weights and repacks
+        elif it == 1:
+            with torch.no_grad():              # a write through torch: noticed by the version counter
+                eng.params[2].mul_(1.25)
+                eng.params[16].add_(0.01)
+    # a stale pack is what the flag would give without the repack: the raw entry with the flag on a scratch whose packs
+    # were made from OTHER weights must differ (the flag is honoured, not ignored)
+    ws = ops.Bf16Workspace(B, D, Z, DEV)
+    other = [t.clone() for t in eng.params]
+    other[2].mul_(0.5)
+    ops.pack_params_bf16(ws, other)
+    grads = [torch.zeros_like(t) for t in eng.params]
+    c = _ffi.make_cond(list(eng.cond_tabs), [torch.zeros_like(t) for t in eng.cond_tabs], eng.gender, eng.age)
+    ops.train_step_bf16(ws, x, eng.params, grads, torch.zeros(3, device=DEV), beta=eng.beta, eps=eps, cond=c,
+                        flags=_ffi.BF16_PACKS_CURRENT)
+    torch.cuda.synchronize()
+    assert ops.last_step_launches_bf16() == 6
+    assert not torch.equal(grads[4], eng.grads[4])
