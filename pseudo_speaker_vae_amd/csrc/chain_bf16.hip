@@ -200,8 +200,12 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     // ---- prologue: every global read goes out before the first one is consumed (one memory round trip, not five) -----
     constexpr int NOUT = 64 * MB2;
     constexpr int OROW = NOUT * 4 + 16;                  // staged fp32 output row
-    constexpr int RPP = OROW * TR <= STG ? TR : TR / 2;  // output rows per staging pass (NOUT = 512: two passes of 32 rows)
-    static_assert(OROW * RPP <= STG, "staging buffer too small for the output rows");
+    // output rows per staging pass (NOUT = 512: two passes of 16 / 32 rows at 32 / 64-row tiles; a 16-row tile stages its one
+    // row group across the activation image -- dead by then -- and the staging buffer behind it: exactly 16 rows of 2,064 B)
+    constexpr bool WIDE1 = RG == 1 && OROW * TR > STG;
+    constexpr int RPP = (OROW * TR <= STG || WIDE1) ? TR : TR / 2;
+    static_assert(OROW * RPP <= STG + (WIDE1 ? IMG : 0), "staging buffer too small for the output rows");
+    static_assert(RPP % 16 == 0, "a staging pass holds whole row groups");
     constexpr int PPR = NOUT * 4 / 16;                   // 16-byte pieces per output row
     constexpr int NPC = (RPP * PPR + 255) / 256;         // pieces per thread and pass
     // decoder: the target rows, piece by piece as the output pass walks them -- requested FIRST: loads return in order, so
@@ -400,13 +404,14 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
         __syncthreads();
         // copy-out: wavefront w sends rows 4 RG w .. 4 RG (w + 1) - 1, one 1 KB row per instruction
         constexpr int RW = 4 * RG;
+        constexpr int RB = RW < 8 ? RW : 8;  // rows per burst (16-row tiles: four rows per wavefront)
 #pragma unroll
-        for (int i0 = 0; i0 < RW; i0 += 8) {
-            bf16x8 v[8];
+        for (int i0 = 0; i0 < RW; i0 += RB) {
+            bf16x8 v[RB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
+            for (int i = 0; i < RB; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 const long row = tile * TR + RW * wave + i0 + i;
                 if (row < a.B) *reinterpret_cast<bf16x8*>(save + row * H + lane * 8) = v[i];
             }
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     // ---- output: fp32 rows through the staging buffer (the bf16 rows of save[1] have been read: barrier first) -------
     float sq = 0.f;
     const float gsc = RECON ? a.scale * (a.go ? *a.go : 1.0f) : 0.f;
+    char* ostg = WIDE1 ? act : stg;
 #pragma unroll
     for (int ps = 0; ps < TR / RPP; ++ps) {
         __syncthreads();
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
         for (int g = ps * (RPP / 16); g < (ps + 1) * (RPP / 16); ++g)
 #pragma unroll
             for (int mi = 0; mi < MB2; ++mi)
-                *reinterpret_cast<f32x4*>(stg + (16 * (g - ps * (RPP / 16)) + r) * OROW + (16 * (MB2 * wave + mi) + 4 * q) * 4) = acc[mi][g];
+                *reinterpret_cast<f32x4*>(ostg + (16 * (g - ps * (RPP / 16)) + r) * OROW + (16 * (MB2 * wave + mi) + 4 * q) * 4) = acc[mi][g];
         __syncthreads();
         // pieces of RPP rows, row-major: thread t takes pieces t, t + 256, ...
 #pragma unroll
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pc = 256 * (i0 + i) + tid;
-                if (i0 + i < NPC && pc < RPP * PPR) v[i] = *reinterpret_cast<const f32x4*>(stg + (pc / PPR) * OROW + (pc % PPR) * 16);
+                if (i0 + i < NPC && pc < RPP * PPR) v[i] = *reinterpret_cast<const f32x4*>(ostg + (pc / PPR) * OROW + (pc % PPR) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -659,13 +665,14 @@ __global__ __launch_bounds__(256, 1) void chain_bwd_bf16_kernel(const ChainBwdBa
         }
         __syncthreads();
         constexpr int RW = 4 * RG;
+        constexpr int RB = RW < 8 ? RW : 8;  // rows per burst (16-row tiles: four rows per wavefront)
 #pragma unroll
-        for (int i0 = 0; i0 < RW; i0 += 8) {
-            bf16x8 v[8];
+        for (int i0 = 0; i0 < RW; i0 += RB) {
+            bf16x8 v[RB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
+            for (int i = 0; i < RB; ++i) v[i] = *reinterpret_cast<const bf16x8*>(stg + (RW * wave + i0 + i) * SROW + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 const long row = tile * TR + RW * wave + i0 + i;
                 if (row < a.B) *reinterpret_cast<bf16x8*>(save + row * H + lane * 8) = v[i];
             }
@@ -779,11 +786,11 @@ static hipError_t launch_chain_bwd_rg(const ChainBwdBatch& b, hipStream_t s) {
 // decoder chain: in = g_y bf16 [B, D] (K0 = D), third layer -> g_z [B, Z]; encoder chains: in = fp32 [B, Z], two layers
 hipError_t launch_chain_bwd_bf16(const ChainBwdBatch& b, hipStream_t s) {
     const ChainBwdArgs& c = b.c[0];
-    const bool rg2 = chain_rows_per_tile(c.B, b.n) == 32;
+    const int rows = chain_rows_per_tile(c.B, b.n);
 #define PSVAE_BD(KB0, MB2) if (c.in_bf16 && c.K0 == 32 * KB0 && c.NOUT == 64 * MB2) \
-        return rg2 ? launch_chain_bwd_rg<KB0, MB2, true, 2>(b, s) : launch_chain_bwd_rg<KB0, MB2, true, 4>(b, s)
+        return rows == 16 ? launch_chain_bwd_rg<KB0, MB2, true, 1>(b, s) : rows == 32 ? launch_chain_bwd_rg<KB0, MB2, true, 2>(b, s) : launch_chain_bwd_rg<KB0, MB2, true, 4>(b, s)
 #define PSVAE_BE(KB0) if (!c.in_bf16 && c.K0 == 32 * KB0 && c.NOUT == 0) \
-        return rg2 ? launch_chain_bwd_rg<KB0, 0, false, 2>(b, s) : launch_chain_bwd_rg<KB0, 0, false, 4>(b, s)
+        return rows == 16 ? launch_chain_bwd_rg<KB0, 0, false, 1>(b, s) : rows == 32 ? launch_chain_bwd_rg<KB0, 0, false, 2>(b, s) : launch_chain_bwd_rg<KB0, 0, false, 4>(b, s)
     PSVAE_BD(8, 1); PSVAE_BE(2);  // cfg3
     PSVAE_BD(4, 1); PSVAE_BD(16, 1); PSVAE_BD(4, 2); PSVAE_BD(8, 2); PSVAE_BD(16, 2); PSVAE_BE(4);
 #undef PSVAE_BD
@@ -825,15 +832,21 @@ static hipError_t launch_chain_rg(const ChainBatch& b, hipStream_t s) {
     return hipGetLastError();
 }
 
-// rows per tile: 64, or 32 where that fills the chip better (PSVAE_CHAIN_RG = 2 | 4 overrides)
+// rows per tile: 64, or 32 / 16 where that fills the chip better (PSVAE_CHAIN_RG = 1 | 2 | 4 overrides).  A chain
+// workgroup streams its MLP's weights whatever its rows, so fewer rows per tile only pay while the tiles still make ONE round
+// of workgroups: the decoder chains of cfg3 (one chain, 4,096 rows) run 256 tiles of 16 rows -- their row-proportional parts
+// (input stage, publishes, output pass) halve: 19.3 -> 18.3 and 20.0 -> 17.2 us --, the two encoders 2 x 128 tiles of 32
+// (2 x 256 of 16 would be two rounds: 17.2 -> 22.8 us)
 int chain_rows_per_tile(int B, int nchains) {
-    if (const char* e = getenv("PSVAE_CHAIN_RG")) return atoi(e) == 2 ? 32 : 64;
-    return ((B + 63) / 64) * nchains >= 256 ? 64 : 32;
+    if (const char* e = getenv("PSVAE_CHAIN_RG")) return atoi(e) == 1 ? 16 : atoi(e) == 2 ? 32 : 64;
+    if (((B + 63) / 64) * nchains >= 256) return 64;
+    return ((B + 15) / 16) * nchains <= 256 ? 16 : 32;
 }
 
 template <int KB0, int MB2, bool RECON>
 static hipError_t launch_chain_t(const ChainBatch& b, hipStream_t s) {
-    return chain_rows_per_tile(b.c[0].B, b.n) == 32 ? launch_chain_rg<KB0, MB2, RECON, 2>(b, s) : launch_chain_rg<KB0, MB2, RECON, 4>(b, s);
+    const int rows = chain_rows_per_tile(b.c[0].B, b.n);
+    return rows == 16 ? launch_chain_rg<KB0, MB2, RECON, 1>(b, s) : rows == 32 ? launch_chain_rg<KB0, MB2, RECON, 2>(b, s) : launch_chain_rg<KB0, MB2, RECON, 4>(b, s);
 }
 
 // every chain of a batch has the same B, K0 and NOUT (the two encoders; or the decoder alone)

@@ -230,7 +230,11 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
         // for everybody (counted vmcnt, barrier); the DMA of tile t + NBUF into this buffer and the first reads of tile
         // t + 1 go between the remaining MFMAs
         mm(I1{}, 0, 0); SB();
+#ifdef PSVAE_WG_NODMA  // diagnostic: no DMA inside the loop (stale tiles: wrong results, the loop's own time)
+        const bool more = t + 1 < t_end, load = false;
+#else
         const bool more = t + 1 < t_end, load = t + NBUF < t_end;
+#endif
         if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int after = t_end - 2 - t;  // tiles behind t + 1; at most NBUF - 2 of them have been issued

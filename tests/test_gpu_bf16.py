@@ -53,6 +53,8 @@ def test_bf16_train_step_matches_emulation(D, Z, B, cond, tile_mode):
     (512, 128, 2048, False, "chain"),      # D = 512: two output staging passes; Z = 128
     (128, 64, 2500, True, "chain"),        # ragged last tile, D = 128
     (512, 64, 2049, True, "chain-64"),     # one row in the last 64-row tile
+    (256, 64, 1000, True, "chain-16"),     # 16-row tiles for every chain (by default only launches of at most 256 such tiles)
+    (512, 128, 520, False, "chain-16"),    # ... the 512-wide output staged across the image and the staging buffer
     (256, 128, 3000, False, "chain"),
     (256, 64, 300, False, "chain"),        # 10 tiles, the last one ragged
     (256, 64, 100, True, "chain"),
@@ -64,6 +66,8 @@ def test_bf16_row_chains_match_emulation(D, Z, B, cond, how, monkeypatch):
     gradients as one launch; same emulation, same bounds as the per-layer path"""
     if how == "chain-64":
         monkeypatch.setenv("PSVAE_CHAIN_RG", "4")
+    if how == "chain-16":
+        monkeypatch.setenv("PSVAE_CHAIN_RG", "1")
     if how == "per-layer":
         monkeypatch.setenv("PSVAE_BF16_NO_CHAIN", "1")
     if how == "chain-forced":
