@@ -145,6 +145,13 @@ __device__ unsigned long long g_cstamp[2][8];
 #else
 #define CSTAMP(K) do {} while (0)
 #endif
+#if defined(PSVAE_STAMP) && defined(PSVAE_STAMP_PRO)  // diagnostic: slots 2..6 re-used for the forward chain's prologue
+#define PSTAMP(K) CSTAMP(K)
+#define LSTAMP(K) do {} while (0)
+#else
+#define PSTAMP(K) do {} while (0)
+#define LSTAMP(K) CSTAMP(K)
+#endif
 
 template <int KB0, int MB2, bool RECON, int RG>  // K0 = 32 KB0 inputs, NOUT = 64 MB2 outputs, 16 RG rows per tile
 __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch batch) {
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
 #pragma unroll
         for (int i = 0; i < 3; ++i) vt[i] = *reinterpret_cast<const f32x4*>(a.ctab + 4 * (tid + 256 * i));
     }
+    PSTAMP(2);
     *reinterpret_cast<f32x4*>(sbias + 4 * tid) = vb01;   // [bias0 | bias1]
     if (tid < 16 * MB2) *reinterpret_cast<f32x4*>(sbias + 2 * H + 4 * tid) = vb2;
     if (has_tab) {
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             ta[g] = ((unsigned)ta[g] < 3u ? 3 + ta[g] : 6) * H;
         }
     }
+    PSTAMP(3);
     float kl = 0.f;
     if (rep) {
         uint64_t seed = a.seed, offset = a.offset;
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
         for (int o2 = 32; o2 > 0; o2 >>= 1) kl += __shfl_xor(kl, o2);
         if (lane == 0) red[wave] = kl;
     }
+    PSTAMP(4);
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int pc = 4 * i + wave, g = pc % RG, kb = pc / RG;
@@ -346,7 +356,9 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
             }
         }
     }
+    PSTAMP(5);
     __syncthreads();
+    PSTAMP(6);
     if (rep && tid == 0) a.kl_partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
 
     f32x4 acc[8][RG];
@@ -419,15 +431,15 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
     };
     CSTAMP(1);
     layer(std::integral_constant<int, KB0>{}, std::integral_constant<int, 8>{}, sbias, has_tab);
-    CSTAMP(2);
+    LSTAMP(2);
     publish(a.save[0]);
-    CSTAMP(3);
+    LSTAMP(3);
     layer(std::integral_constant<int, HK>{}, std::integral_constant<int, 8>{}, sbias + H, false);
-    CSTAMP(4);
+    LSTAMP(4);
     publish(a.save[1]);
-    CSTAMP(5);
+    LSTAMP(5);
     layer(std::integral_constant<int, HK>{}, std::integral_constant<int, MB2>{}, sbias + 2 * H, false);
-    CSTAMP(6);
+    LSTAMP(6);
 
     // ---- output: fp32 rows through the staging buffer (the bf16 rows of save[1] have been read: barrier first) -------
     float sq = 0.f;

@@ -53,6 +53,7 @@ def test_bf16_train_step_matches_emulation(D, Z, B, cond, tile_mode):
     (512, 128, 2048, False, "chain"),      # D = 512: two output staging passes; Z = 128
     (128, 64, 2500, True, "chain"),        # ragged last tile, D = 128
     (512, 64, 2049, True, "chain-64"),     # one row in the last 64-row tile
+    (256, 64, 1000, True, "wgrad-loader-wave"),  # the weight-gradient launch's alternative form (ragged last tile included)
     (256, 64, 1000, True, "chain-16"),     # 16-row tiles for every chain (by default only launches of at most 256 such tiles)
     (512, 128, 520, False, "chain-16"),    # ... the 512-wide output staged across the image and the staging buffer
     (256, 128, 3000, False, "chain"),
@@ -68,6 +69,8 @@ def test_bf16_row_chains_match_emulation(D, Z, B, cond, how, monkeypatch):
         monkeypatch.setenv("PSVAE_CHAIN_RG", "4")
     if how == "chain-16":
         monkeypatch.setenv("PSVAE_CHAIN_RG", "1")
+    if how == "wgrad-loader-wave":
+        monkeypatch.setenv("PSVAE_WGRAD_LW", "1")
     if how == "per-layer":
         monkeypatch.setenv("PSVAE_BF16_NO_CHAIN", "1")
     if how == "chain-forced":
