@@ -465,7 +465,7 @@ def committed_traffic(D, Z, B, dtype, plan, cond=False):
     """HBM-side bytes per step from the committed rocprofv3 PMC passes -- reported with its provenance, and only when
     the committed passes were taken on this shape; never presented as measured in this run"""
     if (D, Z, B, dtype, cond) == (256, 64, 4096, "bf16", True):
-        names = ("r03_cfg3_pmc.json",)
+        names = ("r03_cfg3_final_pmc.json",)
     elif (D, Z, B, dtype, cond) == (256, 64, 1024, "f32", False):
         names = ("r03_cfg2_pmc.json", "r02_cfg2_pmc.json", "r01_cfg2_pmc.json")
     else:

@@ -6,7 +6,7 @@ NP = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = [r for r in csv.DictReader(open(f)) if "psvae" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] + r["Grid_Size_X"] for r in rows]
-per = next((p for p in range(8, 60) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p]), 18)
+per = next((p for p in range(5, 60) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p]), 18)
 NP = min(NP, len(rows) // per - 1)
 tot = 0
 for i in range(per):

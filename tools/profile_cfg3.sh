@@ -25,8 +25,10 @@ for tag in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for r in csv.DictReader(open(f[0])):
         d = int(r["Dispatch_Id"]); by[d][r["Counter_Name"]] += float(r["Counter_Value"]); names[d] = r["Kernel_Name"]
     ids = [i for i in sorted(by) if "psvae" in names[i]]
-    pk = [k for k, i in enumerate(ids) if "chain_pack" in names[i]]
-    step = ids[pk[-2]:pk[-1]]          # the last complete step: pack .. slab sums
+    # the last complete step: from its first launch (the pack launch with PSVAE_BF16_PACK_IN_STEP=1, else the encoder chains)
+    first = "chain_pack" if any("chain_pack" in names[i] for i in ids[-8:]) else "chain_fwd_bf16_kernel<8"
+    pk = [k for k, i in enumerate(ids) if first in names[i]]
+    step = ids[pk[-2]:pk[-1]]
     if not order:
         order = [short(names[i]) for i in step]
     for pos, i in enumerate(step):
@@ -54,4 +56,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/trace" -- python3 
 find "$RAW/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 python3 tools/parse_trace.py "$RAW/trace" 100 > "$OUT/timeline.txt"
 python3 bench.py --dtype bf16 --cond --batch 4096 > "$OUT/bench.json" 2> "$OUT/bench.log"
+PSVAE_BF16_PACK_IN_STEP=1 python3 bench.py --dtype bf16 --cond --batch 4096 --no-cpu-baseline > "$OUT/bench_pack_in_step.json" 2>> "$OUT/bench.log"
 cat "$OUT/pmc.md" "$OUT/timeline.txt"; tail -1 "$OUT/bench.json"
