@@ -195,9 +195,10 @@ int psvae_set_plan(const psvae_dims* dims, const char* text);
  * z_out[B,Z] are fp32; all bf16 intermediates live in `scratch` (psvae_bf16_scratch_bytes).  Activations and
  * gradients exist in ONE bf16 layout: the weight gradients read their batch-major operands transposed out of LDS
  * (ds_read_b64_tr_b16).  cond (nullable) adds the one-hot gather tables.
- * From B = 64 up, with D in {128, 256, 512} and Z in {64, 128}, the pass runs as 7 launches: every 3-layer MLP (each
- * encoder, the decoder) is one "row chain" launch per direction with its activations in LDS, and all weight gradients are
- * one launch (csrc/chain_bf16.hip); other shapes take a launch per layer.
+ * From B = 64 up, with D in {128, 256, 512} and Z in {64, 128}, the pass runs as 7 launches (6 with
+ * PSVAE_BF16_PACKS_CURRENT): the weight packs, then every 3-layer MLP (the encoders, the decoder) as one "row chain" launch
+ * per direction with its activations in LDS (csrc/chain_bf16.hip), all weight gradients as one launch
+ * (csrc/wgrad_bf16.hip) and the sums of its partial slabs; other shapes take a launch per layer.
  * flags: the loss variants of the fp32 step (L2-normalised decoder output, model.py:60-61; cosine loss, lightning.py:110-111),
  * available on the row-chain shapes (PSVAE_ERR_SHAPE elsewhere): the decoder chain leaves the raw output and one row kernel
  * normalises, takes the loss term and the gradient w.r.t. the raw output. */
