@@ -216,6 +216,15 @@ int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_pa
                           const float* grad_loss /* nullable = 1 */, const psvae_grads* grads, float* loss3,
                           void* scratch, uint32_t flags /* PSVAE_NORMALIZE_DECODER | PSVAE_COS_LOSS */, void* stream);
 
+/* The weight-gradient launch of the bf16 pass by itself: dW[out,in] = dY^T X and db[out] = column sums of dY (nullable) --
+ * what autograd leaves in an nn.Linear's .weight.grad / .bias.grad (model.py:14-36).  dY [B, ldy], X [B, ldx]: bf16,
+ * row-major, pitches multiples of 8 elements, bases 16-byte aligned; results fp32.  split (1..8): the batch is cut over that
+ * many workgroups per 128 x 128 tile, their partial results summed in slice order (scratch: psvae_wgrad_bf16_scratch_bytes).
+ * A building block and a test hook: integer-valued operands make every sum exact (tests/test_gpu_wgrad.py). */
+size_t psvae_wgrad_bf16_scratch_bytes(int out, int in, int split);
+int psvae_wgrad_bf16(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, int64_t B, int out, int in, float* dW,
+                     float* db /* nullable */, int split, void* scratch /* nullable when split == 1 */, void* stream);
+
 /* VAEModel.decode (model.py:65-69): x_hat[N,D] = decoder(z[N,Z]); dec = the 6 decoder tensors
  * (params->p[12..17]).  Used by inference.py:25,105.  scratch: psvae_decode_scratch_bytes(N). */
 size_t psvae_decode_scratch_bytes(int64_t N);

@@ -461,6 +461,46 @@ static int bf16_pass(int mode, const psvae_dims* dims, const float* x, const psv
 
 int psvae_last_step_launches_bf16(void) { return t_bf_launches; }
 
+// ---- the weight-gradient launch of the bf16 pass as an entry of its own (csrc/wgrad_bf16.hip): dW = dY^T X, db = column
+// sums of dY.  What autograd computes for an nn.Linear's .weight.grad / .bias.grad (model.py:14-36) from bf16 operands;
+// exposed so that the kernel can be pinned by itself at full batch sizes (tests/test_gpu_wgrad.py: integer-valued operands
+// make every fp32 sum exact, so the result must equal an integer matrix product bit for bit whatever the batch split).
+size_t psvae_wgrad_bf16_scratch_bytes(int out, int in, int split) {
+    if (out <= 0 || in <= 0 || split < 1 || split > BF_SMAX) return 0;
+    return split > 1 ? (size_t)split * ((size_t)out * in + out) * sizeof(float) : 0;
+}
+
+int psvae_wgrad_bf16(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, int64_t B, int out, int in, float* dW,
+                     float* db, int split, void* scratch, void* stream) {
+    if (!dY || !X || !dW) return PSVAE_ERR_NULL;
+    if (B <= 0 || B > INT32_MAX || out <= 0 || in <= 0 || ldy < out || ldx < in) return PSVAE_ERR_SHAPE;
+    if (split < 1 || split > BF_SMAX) return PSVAE_ERR_ARG;
+    if ((ldy & 7) || (ldx & 7) || (reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return PSVAE_ERR_SHAPE;
+    if (split > 1 && !scratch) return PSVAE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    GemmBatchBf b{};
+    GemmDescBf d = bdesc(out, in, (int)B, dY, (int)ldy, X, (int)ldx);
+    d.tr = 1;
+    d.ldcf = in;
+    float* slabW = reinterpret_cast<float*>(scratch);
+    float* slabB = slabW ? slabW + (size_t)split * out * in : nullptr;
+    if (split > 1) {
+        d.ksplit = split;
+        d.Cf = slabW;
+        d.colsum = db ? slabB : nullptr;
+    } else {
+        d.Cf = dW;
+        d.colsum = db;
+    }
+    addb(b, d);
+    RET_IF(launch_wgrad_batch_bf16(b, s));
+    if (split > 1) {
+        const float* rsrc[2] = {slabW, slabB}; float* rdst[2] = {dW, db}; int64_t rnum[2] = {(int64_t)out * in, out}; int rS[2] = {split, split};
+        RET_IF(launch_slab_reduce(rsrc, rdst, rnum, rS, db ? 2 : 1, s));
+    }
+    return PSVAE_OK;
+}
+
 int psvae_train_step_bf16(const psvae_dims* dims, const float* x, const psvae_params* params, const psvae_cond* cond,
                           const float* eps_in, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* eps_out,
                           float* z_out, float* x_hat, float* mu, float* logvar, float beta, const float* grad_loss,

@@ -635,7 +635,8 @@ hipError_t launch_wgrad_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
         const char* e = getenv("PSVAE_BF16_XCD");  // tuning (read per call: tests flip it in-process)
         b.xcd_remap = e ? atoi(e) : 1;
     }
-    static const int nbuf = getenv("PSVAE_WGRAD_NBUF") ? atoi(getenv("PSVAE_WGRAD_NBUF")) : 2;
+    const char* nbe = getenv("PSVAE_WGRAD_NBUF");  // (read per call: a test runs the other depths)
+    const int nbuf = nbe ? atoi(nbe) : 2;
     // loader-wavefront form: measured slower at cfg3 (29.0 vs 22.0 us): its hand-over step is 360 cycles instead of 750-900, but
     // five wavefronts of 144 registers do not pack two workgroups onto a CU's four SIMDs reliably (3 wavefronts per SIMD),
     // and with two LDS buffers one wavefront's 32 DMA instructions (>= 500 cycles of issue) plus their latency exceed the

@@ -273,6 +273,23 @@ def pack_params_bf16(ws: Bf16Workspace, params: Sequence[torch.Tensor]) -> None:
                "pack_params_bf16")
 
 
+def wgrad_bf16(dY: torch.Tensor, X: torch.Tensor, split: int = 1, bias: bool = True):
+    """dW = dY^T X (fp32 [out, in]) and db = column sums of dY from bf16 operands [B, out], [B, in]: psvae_wgrad_bf16, the
+    weight-gradient launch of the bf16 pass by itself"""
+    if dY.dtype != torch.bfloat16 or X.dtype != torch.bfloat16 or dY.dim() != 2 or X.dim() != 2 or dY.shape[0] != X.shape[0]:
+        raise _ffi.PsvaeError("wgrad_bf16: bf16 [B, out] and [B, in]")
+    if dY.stride(1) != 1 or X.stride(1) != 1:
+        raise _ffi.PsvaeError("wgrad_bf16: rows must be contiguous")
+    B, out, inn = dY.shape[0], dY.shape[1], X.shape[1]
+    dW = torch.empty(out, inn, dtype=torch.float32, device=dY.device)
+    db = torch.empty(out, dtype=torch.float32, device=dY.device) if bias else None
+    nbytes = int(_ffi.lib().psvae_wgrad_bf16_scratch_bytes(out, inn, split))
+    scratch = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dY.device)
+    _ffi.check(_ffi.lib().psvae_wgrad_bf16(dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), B, out, inn, _ffi.ptr(dW),
+                                           _ffi.ptr(db), split, _ffi.ptr(scratch), _ffi.stream_ptr()), "wgrad_bf16")
+    return dW, db
+
+
 def decode(z: torch.Tensor, dec_params: Sequence[torch.Tensor], D: int, flags: int = 0,
            cond_tab=None, gender=None, age=None, out: Optional[torch.Tensor] = None,
            scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
