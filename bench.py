@@ -542,6 +542,7 @@ def run_rank(args) -> int:
     mode = args.mode
     allreduce = "none"
     calibrated = None
+    t_over = None
     direct = rk.pg is not None and eng.averager is not None and eng.averager.direct is not None
     in_graph_env = os.environ.get("PSVAE_DDP_IN_GRAPH", "0") in ("1", "2") or os.environ.get("PSVAE_DDP_OVERLAP") == "1"
     if mode == "auto" and not args.with_adam and not in_graph_env:
@@ -583,14 +584,30 @@ def run_rank(args) -> int:
             t_graph = _time(eng.replay)
             t_eager = _time(lambda: eng.step_then_allreduce(x))
             t_graph, t_eager = rk.max_over_ranks(t_graph, t_eager)
+            # third form (fp32 under RCCL, more than one rank): the decoder bucket's all-reduce on a side stream under the
+            # encoder backward (TrainEngine.step_overlapped) -- pays ~25 us of host work for hiding part of the exchange
+            if world > 1 and args.dtype == "f32" and not direct and eng.averager.backend == "nccl" and gather is None \
+                    and os.environ.get("PSVAE_DDP_NO_OVERLAP_FORM") != "1":
+                t_over = rk.max_over_ranks(_time(lambda: eng.step_overlapped(x)), 0.0)[0]
         else:
             t_graph = _time(eng.replay)
             t_eager = _time(lambda: eng.forward_backward(x))
         calibrated = {"graph_us": round(t_graph, 2), "eager_us": round(t_eager, 2)}
         mode = "eager" if t_eager < t_graph else "graph"
+        if t_over is not None:
+            calibrated["overlapped_us"] = round(t_over, 2)
+            if t_over < min(t_eager, t_graph):
+                mode = "overlapped"
     if mode == "auto":
         mode = "graph"
-    if mode == "graph" and rk.pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
+    if mode == "overlapped":
+        allreduce = "2 buckets: the decoder's on a side stream under the encoder backward, the encoders' behind the step"
+
+        def step(i):
+            eng.step_overlapped(x)
+            if args.with_adam:
+                eng.optimizer_step()
+    elif mode == "graph" and rk.pg is not None and os.environ.get("PSVAE_DDP_OVERLAP") == "1":
         mode = "graph-ddp-overlap"  # two captured halves around two RCCL all-reduces (decoder bucket overlapped)
         allreduce = "2 buckets, eager between two graphs"
         eng.capture_ddp(x)
@@ -673,7 +690,8 @@ def run_rank(args) -> int:
                                    f"{'+RCCL grad all-reduce' if world > 1 else ''}, d_in={D} z={Z} hidden=512, "
                                    f"batch={B}/GPU, global_batch={B * world}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate'}",
-                       "launch": {"eager": "stream (one C call enqueues the step's launches)",
+                       "launch": {"overlapped": "stream, two C calls around the decoder bucket's all-reduce (side stream)",
+                                  "eager": "stream (one C call enqueues the step's launches)",
                                   "graph": "graph (captured HIP graph, one replay per step)"}.get(mode, mode),
                        "n_gpus": world, "ranks_seen": ranks_seen, "parallelism": f"dp{world}",
                        "allreduce": allreduce if rk.pg is None else allreduce + (
@@ -712,7 +730,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
     ap.add_argument("--input-dim", type=int, default=256)
     ap.add_argument("--latent-dim", type=int, default=64)
-    ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "graph", "eager", "overlapped"], default="auto")
     ap.add_argument("--with-adam", action="store_true", help="also run the fused Adam step inside the timed region")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = config 3 arithmetic (bf16 MFMA operands, fp32 accumulate and master weights)")

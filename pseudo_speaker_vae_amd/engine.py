@@ -235,6 +235,35 @@ class TrainEngine:
             self.averager.reduce_all()
             self.averager.wait()
 
+    def step_overlapped(self, x: torch.Tensor):
+        """data-parallel step (fp32, RCCL) with the decoder bucket's exchange UNDER the encoder backward: two C calls enqueue
+        [forward + ELBO + decoder backward] and [encoder backward] on the stream; between them the decoder bucket's all-reduce
+        is issued on a side stream that waits for an event behind the first half; the encoder bucket (with the loss scalars)
+        follows the second half on the main stream, which then waits for the side stream.  Both all-reduces in the blocking
+        form (the stream waits, not the host: reduce_all's note).  Same gradients as step_then_allreduce; which of the two is
+        faster depends on the ranks' exchange time against ~25 us of extra host work -- `bench.py` measures both."""
+        import torch.distributed as dist
+        if self.dtype != "f32" or self.averager is None or self.averager.backend != "nccl" or self.averager.direct is not None:
+            raise _ffi.PsvaeError("step_overlapped: the fp32 pass under an RCCL process group")
+        if self.conditional and self._cond is None:
+            raise _ffi.PsvaeError("conditional engine: call set_labels(gender, age) for this batch first")
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev_half = torch.cuda.Event()
+            self._ev_comm = torch.cuda.Event()
+        main = torch.cuda.current_stream(self.device)
+        kw = dict(beta=self.beta, eps=None, rng_state=self.rng_state, **self._step_kwargs())
+        ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_DECODER, **kw)
+        self._ev_half.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self._ev_half)
+            dist.all_reduce(self.averager.buckets[1], op=dist.ReduceOp.AVG, group=self.averager.pg)
+            self._ev_comm.record(self._side)
+        ops.train_step(self.ws, x, self.params, self.grads, self.outs, self.loss3, phases=_ffi.PHASE_ENCODER, **kw)
+        self._skip_rng()
+        dist.all_reduce(self.averager.buckets[0], op=dist.ReduceOp.AVG, group=self.averager.pg)
+        main.wait_event(self._ev_comm)
+
     def _skip_rng(self):
         """jump over the other ranks' Philox blocks (a torch op: captured steps carry it)"""
         if self._rng_skip:

@@ -51,7 +51,7 @@ def _same(e_ref, e, what):
     assert torch.equal(e_ref.ws.acts["eps"], e.ws.acts["eps"]), what + ": epsilon differs"
 
 
-@pytest.mark.parametrize("mode", ["eager_split", "graph_then_allreduce", "two_graphs", "in_graph", "in_graph_overlap"])
+@pytest.mark.parametrize("mode", ["eager_split", "stream_overlapped", "graph_then_allreduce", "two_graphs", "in_graph", "in_graph_overlap"])
 def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group, mode):
     from pseudo_speaker_vae_amd.engine import TrainEngine
     x = torch.randn(B, D, device=DEV)
@@ -60,6 +60,8 @@ def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group,
     assert eng.world == 1 and eng.averager is not None and eng.averager.backend == "nccl"
     if mode == "eager_split":
         step = lambda: eng.forward_backward(x)
+    elif mode == "stream_overlapped":  # the decoder bucket's all-reduce on a side stream under the encoder backward
+        step = lambda: eng.step_overlapped(x)
     elif mode == "graph_then_allreduce":
         eng.capture(x)
         step = eng.replay

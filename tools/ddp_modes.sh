@@ -10,3 +10,4 @@ EXTRA="--mode graph" run "graph + RCCL all-reduce   " A=1
 EXTRA="--mode graph --allreduce direct" run "graph + direct exchange   " A=1
 EXTRA="--mode graph" run "all-reduce inside graph   " PSVAE_DDP_IN_GRAPH=1
 EXTRA="--mode eager" run "phase split, 2 buckets    " A=1
+EXTRA="--mode overlapped" run "overlapped (side stream)  " A=1
