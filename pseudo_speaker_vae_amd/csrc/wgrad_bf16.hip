@@ -7,8 +7,8 @@
 // loads into registers, ds_write_b128, barrier, transposed fragment reads with 2-way bank conflicts, MFMAs -- because
 // the four wavefronts of a workgroup move in lock step (2.1-2.7 k cycles per tile for 0.5 k cycles of MFMA).
 // This kernel removes the register hop and the conflicts and overlaps the rest:
-//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), NBUF tiles deep, counted s_waitcnt vmcnt(n)
-//     and ONE raw s_barrier per tile; no VGPR staging, no ds_write.
+//   * operand tiles (32 or 64 batch rows) go global -> LDS by LDS-DMA (global_load_lds_dwordx4), NBUF tiles deep, counted
+//     s_waitcnt vmcnt(n) and ONE raw s_barrier per tile; no VGPR staging, no ds_write.
 //   * the LDS image is not rows of the matrix: a DMA instruction writes 1 KB = 64 lanes x 16 B lane-linearly, but every
 //     lane's SOURCE address is free, so the image is laid out as the fragment reads want it.  One
 //     ds_read_b64_tr_b16 of the 32x32x16 MFMA operand touches 8 batch rows x 64 B (32 features): that block is made 512
@@ -57,25 +57,30 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most `tiles` of this wave's tiles (8 DMA instructions each) are still in flight; `tiles` is wave-uniform
-template <int MAXT>
+// wait until at most `tiles` of this wave's tiles (PER DMA instructions each) are still in flight; `tiles` is wave-uniform
+template <int MAXT, int PER>
 __device__ __forceinline__ void wait_vm_tiles(int tiles) {
-    if (MAXT >= 3 && tiles >= 3) wait_vm<24>();
-    else if (MAXT >= 2 && tiles == 2) wait_vm<16>();
-    else if (MAXT >= 1 && tiles == 1) wait_vm<8>();
+    if (MAXT >= 3 && tiles >= 3) wait_vm<3 * PER>();
+    else if (MAXT >= 2 && tiles == 2) wait_vm<2 * PER>();
+    else if (MAXT >= 1 && tiles == 1) wait_vm<PER>();
     else wait_vm<0>();
 }
 
-template <int NBUF>
+// BK: batch rows per tile (64, or 32: half the LDS per buffer -- three buffers in 48 KB)
+template <int NBUF, int BK>
 __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, int ksg, unsigned lds0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int M = d.M, N = d.N, K = d.K;
     const int m0 = tm * WG_BM, n0 = tn * WG_BN;
+    constexpr int KS = BK / 16;              // 16-deep k steps per tile
+    constexpr int OPB = BK * 256;            // one operand's tile image (bytes)
+    constexpr int TILEB = 2 * OPB;           // A image, then B image
+    constexpr int NJ = BK / 16;              // DMA instructions per wavefront, operand and tile
 
     // ---- k tiles of this workgroup (slice ksg of the batch split)
-    const int nt_all = (K + WG_BK - 1) / WG_BK;
+    const int nt_all = (K + BK - 1) / BK;
     const int S = d.ksplit > 1 ? d.ksplit : 1;
     const int per = (nt_all + S - 1) / S;
     const int t_beg = ksg * per;
@@ -83,51 +88,56 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
 
     // ---- DMA side: wave w owns the four instructions J = 4 w + j of each operand (k step w of the tile; j = (hi, pair))
     const int cbl = lane >> 5, kh = (lane >> 4) & 1, qq = (lane >> 2) & 3, c16 = (lane >> 1) & 1, ph = lane & 1;
-    const u16* pa[4];
-    const u16* pb[4];
-    int krow[4];
+    const u16* pa[NJ];
+    const u16* pb[NJ];
+    int krow[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int hi = j >> 1, pair = j & 1;
-        krow[j] = 16 * wave + 8 * kh + 4 * hi + qq;
+    for (int j = 0; j < NJ; ++j) {
+        const int J = NJ * wave + j, hi = (J >> 1) & 1, pair = J & 1;  // instruction J of 4 NJ: k step J >> 2
+        krow[j] = 16 * (J >> 2) + 8 * kh + 4 * hi + qq;
         const int col = 64 * pair + 32 * cbl + 16 * c16 + 8 * ph;
         // pieces beyond the row pitch re-read piece 0 of the row: they only feed outputs that are never stored
         const int ca = (m0 + col + 8 <= d.lda) ? m0 + col : m0;
         const int cb = (n0 + col + 8 <= d.ldb) ? n0 + col : n0;
-        pa[j] = d.A + ((size_t)t_beg * WG_BK + krow[j]) * d.lda + ca;
-        pb[j] = d.B + ((size_t)t_beg * WG_BK + krow[j]) * d.ldb + cb;
+        pa[j] = d.A + ((size_t)t_beg * BK + krow[j]) * d.lda + ca;
+        pb[j] = d.B + ((size_t)t_beg * BK + krow[j]) * d.ldb + cb;
     }
-    const size_t stepa = (size_t)WG_BK * d.lda, stepb = (size_t)WG_BK * d.ldb;
-    const unsigned dma0 = lds0 + 4096u * (unsigned)wave;  // + buf * TILE_BYTES + 1024 j (+ OP_BYTES for B)
+    const size_t stepa = (size_t)BK * d.lda, stepb = (size_t)BK * d.ldb;
+    const unsigned dma0 = lds0 + 1024u * NJ * (unsigned)wave;  // + buffer + 1024 j (+ OPB for B)
     // tile t -> buffer at buf_off, in four parts (two DMA instructions each) so that the k loop can put them between MFMAs:
     // a wavefront that issues all eight at once sits in the vector-memory issue queue behind the other three wavefronts'
     // instructions (32 KB through a 64 B/clk path) with its MFMAs waiting behind them in program order
     auto issue_part = [&](auto PART, int t, unsigned buf_off) {
         constexpr int part = decltype(PART)::value;
-        if ((t + 1) * WG_BK <= K) {
-            if constexpr (part < 2) {
-                glds16(pa[2 * part], __builtin_amdgcn_readfirstlane(dma0 + buf_off + 2048u * part));
-                glds16(pa[2 * part + 1], __builtin_amdgcn_readfirstlane(dma0 + buf_off + 2048u * part + 1024u));
-            } else {
-                glds16(pb[2 * part - 4], __builtin_amdgcn_readfirstlane(dma0 + buf_off + OP_BYTES + 2048u * (part - 2)));
-                glds16(pb[2 * part - 3], __builtin_amdgcn_readfirstlane(dma0 + buf_off + OP_BYTES + 2048u * (part - 2) + 1024u));
+        if ((t + 1) * BK <= K) {
+            if constexpr (NJ == 4) {  // 64-row tiles: two instructions per part
+                if constexpr (part < 2) {
+                    glds16(pa[2 * part], __builtin_amdgcn_readfirstlane(dma0 + buf_off + 2048u * part));
+                    glds16(pa[2 * part + 1], __builtin_amdgcn_readfirstlane(dma0 + buf_off + 2048u * part + 1024u));
+                } else {
+                    glds16(pb[2 * part - 4], __builtin_amdgcn_readfirstlane(dma0 + buf_off + OPB + 2048u * (part - 2)));
+                    glds16(pb[2 * part - 3], __builtin_amdgcn_readfirstlane(dma0 + buf_off + OPB + 2048u * (part - 2) + 1024u));
+                }
+            } else {                  // 32-row tiles: one instruction per part
+                if constexpr (part < 2) glds16(pa[part], __builtin_amdgcn_readfirstlane(dma0 + buf_off + 1024u * part));
+                else glds16(pb[part - 2], __builtin_amdgcn_readfirstlane(dma0 + buf_off + OPB + 1024u * (part - 2)));
             }
         } else if (part == 0) {
             // ragged tile (the last one of the batch): same image through registers, rows past the batch as zeros
             const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = t * WG_BK + krow[j] < K;
+            for (int j = 0; j < NJ; ++j) {
+                const bool in = t * BK + krow[j] < K;
                 const bf16x8 va = in ? *reinterpret_cast<const PSVAE_GLOBAL bf16x8*>(reinterpret_cast<uintptr_t>(pa[j])) : zero8;
                 const bf16x8 vb = in ? *reinterpret_cast<const PSVAE_GLOBAL bf16x8*>(reinterpret_cast<uintptr_t>(pb[j])) : zero8;
                 *(PSVAE_LDS bf16x8*)(uintptr_t)(dma0 + buf_off + 1024u * j + 16u * lane) = va;
-                *(PSVAE_LDS bf16x8*)(uintptr_t)(dma0 + buf_off + OP_BYTES + 1024u * j + 16u * lane) = vb;
+                *(PSVAE_LDS bf16x8*)(uintptr_t)(dma0 + buf_off + OPB + 1024u * j + 16u * lane) = vb;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the ds_writes, before the barrier that publishes them)
         }
         if constexpr (part == 3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 pa[j] += stepa;
                 pb[j] += stepb;
             }
@@ -144,7 +154,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
     const int g = lane >> 4, i = lane & 15;
     const unsigned lanepart = 16u * (16u * (g >> 1) + 4u * (i >> 2) + 2u * (g & 1) + ((i & 3) >> 1)) + 8u * (i & 1);
     const unsigned aoff = lds0 + lanepart + 1024u * wm;
-    const unsigned boff = lds0 + lanepart + OP_BYTES + 1024u * wn;
+    const unsigned boff = lds0 + lanepart + OPB + 1024u * wn;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -201,8 +211,8 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
         int issued = 0;
 #pragma unroll
         for (int b = 0; b < NBUF; ++b)
-            if (t_beg + b < t_end) { issue(t_beg + b, (unsigned)b * TILE_BYTES); ++issued; }
-        wait_vm_tiles<NBUF - 1>(issued - 1);
+            if (t_beg + b < t_end) { issue(t_beg + b, (unsigned)b * TILEB); ++issued; }
+        wait_vm_tiles<NBUF - 1, 2 * NJ>(issued - 1);
         __builtin_amdgcn_s_barrier();
         SB();
         rd(I0{}, 0u, 0);
@@ -221,10 +231,12 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
     // iteration of tile t in buffer BUF: fragment set 0 holds (or is receiving) its k step 0
     auto iter = [&](auto BUFC, int t) {
         constexpr int BUF = decltype(BUFC)::value;
-        constexpr unsigned bo = (unsigned)BUF * TILE_BYTES, bnext = (unsigned)((BUF + 1) % NBUF) * TILE_BYTES;
+        constexpr unsigned bo = (unsigned)BUF * TILEB, bnext = (unsigned)((BUF + 1) % NBUF) * TILEB;
         kstep(I0{}, I1{}, bo, 1);
-        kstep(I1{}, I0{}, bo, 2);
-        kstep(I0{}, I1{}, bo, 3);
+        if constexpr (KS == 4) {
+            kstep(I1{}, I0{}, bo, 2);
+            kstep(I0{}, I1{}, bo, 3);
+        }
         STAMP();
         // last k step = hand-over: behind its first MFMA all of tile t is in registers (lgkmcnt 0) and tile t + 1 has landed
         // for everybody (counted vmcnt, barrier); the DMA of tile t + NBUF into this buffer and the first reads of tile
@@ -238,7 +250,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmDescBf& d, int tm, int tn, 
         if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int after = t_end - 2 - t;  // tiles behind t + 1; at most NBUF - 2 of them have been issued
-            wait_vm_tiles<NBUF - 2>(after < NBUF - 2 ? after : NBUF - 2);
+            wait_vm_tiles<NBUF - 2, 2 * NJ>(after < NBUF - 2 ? after : NBUF - 2);
             STAMP();
             __builtin_amdgcn_s_barrier();
             STAMP();
@@ -576,7 +588,7 @@ hipError_t launch_wgrad_lw(GemmBatchBf& b, hipStream_t stream) {
 // panels) run under one L2, and so do problems that read the same array (the table gradients next to the layer whose dY
 // they share; both first encoder layers, which share x).  With a contiguous range per PROBLEM (round 2's mapping) the
 // launch pulled 90 MB through the L2s for 53 MB of operands, and the fabric, not the CU, set its time.
-template <int NBUF>
+template <int NBUF, int BK>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const GemmBatchBf batch) {
     extern __shared__ __attribute__((aligned(16))) char wg_smem[];
     int L = blockIdx.x;
@@ -594,18 +606,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const GemmBatchBf batch
     const GemmDescBf& d = batch.d[di];
     const int lt = tile - d.tile_begin;
     const int tm = lt / d.tiles_n, tn = lt - tm * d.tiles_n;
-    wgrad_tile<NBUF>(d, tm, tn, ksg, (unsigned)reinterpret_cast<uintptr_t>(wg_smem));
+    wgrad_tile<NBUF, BK>(d, tm, tn, ksg, (unsigned)reinterpret_cast<uintptr_t>(wg_smem));
 }
 
 namespace {
 
-template <int NBUF>
+template <int NBUF, int BK>
 hipError_t launch_wgrad_nbuf(GemmBatchBf& b, hipStream_t stream) {
-    constexpr int lds = NBUF * TILE_BYTES;
+    constexpr int lds = NBUF * 2 * BK * 256;
     static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
-    if (hipError_t e = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&wgrad_bf16_kernel<NBUF>), lds > 64 * 1024 ? lds : 64 * 1024))
+    if (hipError_t e = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&wgrad_bf16_kernel<NBUF, BK>), lds > 64 * 1024 ? lds : 64 * 1024))
         return e;
-    hipLaunchKernelGGL((wgrad_bf16_kernel<NBUF>), dim3(b.total_tiles), dim3(256), lds, stream, b);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<NBUF, BK>), dim3(b.total_tiles), dim3(256), lds, stream, b);
     return hipGetLastError();
 }
 
@@ -644,9 +656,17 @@ hipError_t launch_wgrad_batch_bf16(GemmBatchBf& b, hipStream_t stream) {
     // Kept selectable (read per call: a test runs it) as the measured alternative.
     const char* lwe = getenv("PSVAE_WGRAD_LW");
     if (lwe && atoi(lwe)) return nbuf == 3 ? launch_wgrad_lw<3>(b, stream) : launch_wgrad_lw<2>(b, stream);
-    if (nbuf == 3) return launch_wgrad_nbuf<3>(b, stream);
-    if (nbuf == 4) return launch_wgrad_nbuf<4>(b, stream);
-    return launch_wgrad_nbuf<2>(b, stream);
+    // batch rows per tile: 32 (default; two buffers = 32 KB per workgroup) or 64.  Measured at cfg3, per step, interleaved runs:
+    // 32 rows x 2 buffers 95.1-95.6 us, 32 x 3 96.1-96.3, 64 x 2 96.4-96.9, 64 x 3 / 64 x 4 (one workgroup per CU) +10 / +12
+    const char* bke = getenv("PSVAE_WGRAD_BK");
+    if (bke && atoi(bke) == 64) {
+        if (nbuf == 3) return launch_wgrad_nbuf<3, 64>(b, stream);
+        if (nbuf == 4) return launch_wgrad_nbuf<4, 64>(b, stream);
+        return launch_wgrad_nbuf<2, 64>(b, stream);
+    }
+    if (nbuf == 3) return launch_wgrad_nbuf<3, 32>(b, stream);
+    if (nbuf == 4) return launch_wgrad_nbuf<4, 32>(b, stream);
+    return launch_wgrad_nbuf<2, 32>(b, stream);
 }
 
 }  // namespace psvae

@@ -22,6 +22,8 @@ def _ints(shape, lo, hi, seed):
     (4096, 512, 256, 5, "loader-wave"),    # the alternative forms of the launch
     (1030, 128, 128, 2, "loader-wave"),
     (4096, 512, 512, 5, "three-buffers"),
+    (4096, 512, 512, 5, "64-row-tiles"),
+    (1030, 256, 128, 3, "64-row-tiles"),
 ])
 def test_wgrad_bf16_is_exact_on_integer_operands(B, out, inn, split, form, monkeypatch):
     from pseudo_speaker_vae_amd import ops
@@ -29,6 +31,8 @@ def test_wgrad_bf16_is_exact_on_integer_operands(B, out, inn, split, form, monke
         monkeypatch.setenv("PSVAE_WGRAD_LW", "1")
     if form == "three-buffers":
         monkeypatch.setenv("PSVAE_WGRAD_NBUF", "3")
+    if form == "64-row-tiles":
+        monkeypatch.setenv("PSVAE_WGRAD_BK", "64")
     dY = _ints((B, out), -3, 3, 1)
     X = _ints((B, inn), -3, 3, 2)
     # pitches: multiples of 8 elements (the one-hot matrix of the pass is [B][8] with 6 valid columns)
