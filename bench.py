@@ -291,7 +291,7 @@ def bench_stub(args, rk: Rank):
             "stub_grad_mean": float(grad[0])}), flush=True)
 
 
-def bench_decode(args, rk: Rank):
+def bench_decode(args, rk: Rank, emit: bool = True):
     """cfg5: decode-only sampling (inference.py:22-25): z ~ N(0, I) from the device Philox stream, x_hat =
     decoder(z).  Rows are split evenly over the ranks; no collective."""
     from pseudo_speaker_vae_amd import _ffi, ops
@@ -326,7 +326,7 @@ def bench_decode(args, rk: Rank):
         fpe = 2 * (Z * H + H * H + H * D)  # 851,968 FLOP per decoded embedding at cfg5
         achieved = fpe * n / (dev_ms / 1e3 / steps) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        print(json.dumps({
+        res = {
             "metric": "speaker-embeddings/sec (decode)", "value": round(n * world * steps / wall, 1),
             "unit": "speaker-embeddings/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
@@ -336,7 +336,11 @@ def bench_decode(args, rk: Rank):
                                       "z drawn from Philox inside the fused 3-layer decode kernel")
                                    + (" (bf16 operands / fp32 accumulate)" if bf16 else ""), "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None, "flop_per_embedding": fpe}}), flush=True)
+                         "frac": round(achieved / peak, 4), "traffic": None, "flop_per_embedding": fpe}}
+        if emit:
+            print(json.dumps(res), flush=True)
+        return res
+    return None
 
 
 def bench_langevin(args, rk: Rank):
@@ -509,6 +513,59 @@ def run_rank(args) -> int:
         rk.close()
         return 0
 
+    out = measure_train(args, rk)
+    if rank == 0 and out is not None:
+        if secondary_wanted(args, world):
+            out["secondary"] = measure_secondary(args, rk)
+        print(json.dumps(out), flush=True)
+    rk.close()
+    return 0
+
+
+def secondary_wanted(args, world) -> bool:
+    """the default headline run (one GPU, cfg2 as BASELINE.json names it) also carries short measurements of the other
+    single-GPU configurations in its JSON line, so that they are timed by whoever runs the headline"""
+    return (world == 1 and not args.no_secondary and args.workload == "train" and args.dtype == "f32" and not args.cond
+            and (args.input_dim, args.latent_dim, args.batch) == (256, 64, 1024) and not args.gather and not args.with_adam
+            and args.mode == "auto" and not args.plan and not args.tune)
+
+
+def measure_secondary(args, rk):
+    """cfg3 (bf16, conditional, B = 4096), cfg4's per-GPU shape (fp32, d = 512, z = 128, B = 1024) and cfg5's decode-only
+    sampling (1 M rows, fp32 and bf16): same code paths as `--dtype bf16 --cond --batch 4096`, `--input-dim 512
+    --latent-dim 128`, `--workload decode [--dtype bf16]`, fewer steps.  A failure is recorded, never raised."""
+    import copy
+    res = {}
+
+    def brief(d):
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+                "workload": d["config"]["workload"], "roofline_frac": d["roofline"]["frac"],
+                "roofline_peak": d["roofline"]["peak"], "traffic": d["roofline"].get("traffic"),
+                **({"launches_per_step": d["config"]["launches_per_step"], "weight_copies": d["config"]["weight_copies"]}
+                   if "launches_per_step" in d["config"] else {})}
+
+    def run(name, fn, **over):
+        a = copy.copy(args)
+        a.no_cpu_baseline = True
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            res[name] = brief(fn(a))
+        except Exception as e:  # noqa: BLE001 -- the headline line must not depend on a secondary measurement
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize(rk.dev)
+        torch.cuda.empty_cache()
+
+    run("cfg3", lambda a: measure_train(a, rk), dtype="bf16", cond=True, batch=4096, steps=100, warmup=20)
+    run("cfg4_per_gpu_shape", lambda a: measure_train(a, rk), input_dim=512, latent_dim=128, steps=100, warmup=20)
+    run("cfg5_decode_f32", lambda a: bench_decode(a, rk, emit=False), workload="decode", steps=3, warmup=1)
+    run("cfg5_decode_bf16", lambda a: bench_decode(a, rk, emit=False), workload="decode", dtype="bf16", steps=5, warmup=1)
+    return res
+
+
+def measure_train(args, rk):
+    """one training-pass measurement (the headline's code path for any shape / dtype): the result dict on rank 0"""
+    world, rank, dev = rk.world, rk.rank, rk.dev
     from pseudo_speaker_vae_amd.engine import TrainEngine
     D, Z, B = args.input_dim, args.latent_dim, args.batch
     eng = TrainEngine(D, Z, B, device=dev, seed=0, beta=1.0, process_group=rk.pg, dtype=args.dtype,
@@ -717,9 +774,8 @@ def run_rank(args) -> int:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, Z, B)
-        print(json.dumps(out), flush=True)
-    rk.close()
-    return 0
+        return out
+    return None
 
 
 def parse_args(argv=None):
@@ -752,6 +808,9 @@ def parse_args(argv=None):
     ap.add_argument("--samples", type=int, default=1_000_000, help="decode / langevin workloads: rows over all GPUs")
     ap.add_argument("--langevin-steps", type=int, default=100, help="Langevin steps per row (inference.py:34 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default headline run on one GPU: do not append the short cfg3 / cfg4-shape / cfg5 measurements "
+                         "(`secondary` in the JSON line)")
     ap.add_argument("--tune", action="store_true", help="measure a launch plan now instead of using the committed one")
     ap.add_argument("--no-tune", action="store_true", help="(kept for older command lines: tuning is opt-in now)")
     ap.add_argument("--plan", default="", help="use this launch plan (text form printed as config.launch_plan)")
