@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void chain_fwd_bf16_kernel(const ChainBatch
         }
     }
     if constexpr (!RECON) {
-        if (a.oh_out && has_tab && wave == 0 && q == 0) {  // one-hot label rows [B][8] (model.py:71-76: the concatenated labels)
+        if (a.oh_out && has_tab && wave == 0 && q == 0) {  // one-hot label rows [B][8] (the concatenated gender / age labels of config 3: SURVEY.md 8a row A9)
 #pragma unroll
             for (int g = 0; g < RG; ++g) {
                 const long row = tile * TR + 16 * g + r;

@@ -1,5 +1,6 @@
-// All weight gradients of a bf16 pass as ONE launch of 128 x 128 tiles (model.py:40-66: the nn.Linear layers whose
-// .weight.grad / .bias.grad autograd fills in training.py's backward; the conditional tables of model.py:71-76).
+// All weight gradients of a bf16 pass as ONE launch of 128 x 128 tiles: the .weight.grad / .bias.grad that autograd leaves in
+// the nine nn.Linear layers of model.py:14-36 after lightning.py:131, and the gradients of the conditional tables (config 3's
+// one-hot gender / age inputs: no reference code).
 //
 //     dW[o][i] = sum_b dY[b][o] X[b][i]          both operands batch-major ("k-major"), as the row chains leave them
 //
@@ -18,7 +19,7 @@
 //   * fragment reads run one 16-deep k step ahead of the MFMAs (two fragment sets); the tile hand-over (wait, barrier,
 //     next DMA, first reads of the next tile) sits in front of the last k step's MFMAs.
 //   * accumulators leave straight from registers (a 32x32 block's rows are 128-B runs); no epilogue LDS.
-// A ragged last tile (batch % 64 != 0) takes the same image through registers with zero fill.
+// A ragged last tile (batch not a multiple of the tile's rows) takes the same image through registers with zero fill.
 #include <atomic>
 
 #include "psvae_common.h"
@@ -35,7 +36,9 @@ typedef unsigned short u16;
 #define PSVAE_GLOBAL __attribute__((address_space(1)))
 #define PSVAE_LDS __attribute__((address_space(3)))
 
-constexpr int WG_BM = 128, WG_BN = 128, WG_BK = 64;
+constexpr int WG_BM = 128, WG_BN = 128;
+// (the loader-wavefront form's fixed tile: 64 batch rows; wgrad_tile takes its rows per tile as a template parameter)
+constexpr int WG_BK = 64;
 constexpr int OP_BYTES = WG_BK * 128 * 2;  // one operand's tile image: 16 KB = 16 DMA instructions
 constexpr int TILE_BYTES = 2 * OP_BYTES;   // A image, then B image
 
