@@ -436,7 +436,7 @@ def bench_api_step(args, rk: Rank):
         "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{config_label(D, Z, B, 'f32', False)} through the drop-in API: optimizer.zero_grad + "
-                               f"PseudoSpeakerVAE.training_step + loss.backward(){' + torch Adam.step' if args.with_adam else ''}"
+                               f"PseudoSpeakerVAE.training_step + loss.backward(){' + optimizer.step (' + type(opt).__name__ + ')' if args.with_adam else ''}"
                                f" per step (lightning.py:67-131), d_in={D} z={Z} hidden=512, batch={B}, fp32",
                    "launch": "one captured HIP graph per step behind the autograd Function" if graphs.served
                    else "eager launches from the autograd Function",

@@ -363,6 +363,14 @@ int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
                         int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
                         double grad_scale, void* stream);
 
+/* The same update over a LIST of tensors (any addresses) in ONE launch: torch.optim.Adam(params) as lightning.py:205
+ * builds it -- 18 separate parameter tensors, plus the classifier's -- without flattening anything; what
+ * pseudo_speaker_vae_amd.optim.FusedAdam.step() calls.  At most PSVAE_ADAM_MAX_TENSORS tensors per call. */
+#define PSVAE_ADAM_MAX_TENSORS 48
+int psvae_adam_multi_f32(int n_tensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, int64_t step, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, double grad_scale, void* stream);
+
 /* Adam with its step counter and learning rate ON THE DEVICE (a captured hipGraph then applies the right bias
  * correction on every replay, and CosineAnnealingLR, lightning.py:206-213, is one 8-byte write per epoch), which also
  * maintains the k-major weight copies psvae_step_opts::params_kmajor points at.  The flat buffers share one layout:

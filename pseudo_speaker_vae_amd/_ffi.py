@@ -30,7 +30,7 @@ SYMBOLS = (
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
     "psvae_tune_train_step_f32", "psvae_describe_plan", "psvae_set_plan",
     "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_consistency_scratch_bytes", "psvae_consistency_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
-    "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_pack_params_bf16", "psvae_wgrad_bf16_scratch_bytes", "psvae_wgrad_bf16", "psvae_decode_scratch_bytes",
+    "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_pack_params_bf16", "psvae_adam_multi_f32", "psvae_wgrad_bf16_scratch_bytes", "psvae_wgrad_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
     "psvae_last_decode_launches", "psvae_last_step_launches_bf16", "psvae_sample_decode_f32", "psvae_sample_decode_bf16",
@@ -161,6 +161,9 @@ def lib() -> C.CDLL:
     L.psvae_train_step_bf16.restype = C.c_int
     L.psvae_pack_params_bf16.argtypes = [C.POINTER(Dims), C.POINTER(Params), vp, vp]
     L.psvae_pack_params_bf16.restype = C.c_int
+    L.psvae_adam_multi_f32.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, vp]
+    L.psvae_adam_multi_f32.restype = C.c_int
     L.psvae_wgrad_bf16_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     L.psvae_wgrad_bf16_scratch_bytes.restype = C.c_size_t
     L.psvae_wgrad_bf16.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]

@@ -1183,4 +1183,19 @@ int psvae_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
     return 0;
 }
 
+int psvae_adam_multi_f32(int n_tensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, int64_t step, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, double grad_scale, void* stream) {
+    if (n_tensors < 0 || n_tensors > PSVAE_ADAM_MAX_TENSORS || step < 1) return PSVAE_ERR_SHAPE;
+    if (n_tensors == 0) return PSVAE_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !numel) return PSVAE_ERR_NULL;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (numel[i] < 0) return PSVAE_ERR_SHAPE;
+        if (numel[i] > 0 && (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i])) return PSVAE_ERR_NULL;
+    }
+    RET_IF(launch_adam_multi(n_tensors, param, grad, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, weight_decay,
+                             grad_scale, (hipStream_t)stream));
+    return PSVAE_OK;
+}
+
 }  // extern "C"

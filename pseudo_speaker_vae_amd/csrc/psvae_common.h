@@ -306,6 +306,9 @@ hipError_t launch_langevin(int64_t N, int Z, int hidden, int C, const float* W1,
                            hipStream_t s);
 hipError_t launch_gather_rows(const float* table, int64_t N, int D, const int64_t* idx, int64_t B, float* out,
                               hipStream_t s);
+hipError_t launch_adam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v,
+                             const int64_t* numel, int64_t step, double lr, double b1, double b2, double eps, double wd,
+                             double gscale, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, double lr,
                        double b1, double b2, double eps, double wd, double gscale, hipStream_t s);
 

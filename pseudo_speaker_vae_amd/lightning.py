@@ -241,7 +241,14 @@ class PseudoSpeakerVAE(_Base):
         self.model.load_state_dict(sd)
 
     def configure_optimizers(self):                                        # lightning.py:204-214
-        optimizer = Adam(self.parameters(), **self.hparams["optimizer"])
+        # a torch.optim.Adam either way (same param_groups / state / checkpoint format): FusedAdam's step() is one HIP launch
+        # over all parameter tensors and falls through to torch's own step() for anything it does not cover (optim.py)
+        import os
+        if os.environ.get("PSVAE_FUSED_ADAM", "1") != "0":
+            from .optim import FusedAdam
+            optimizer = FusedAdam(self.parameters(), **self.hparams["optimizer"])
+        else:
+            optimizer = Adam(self.parameters(), **self.hparams["optimizer"])
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, **self.hparams["scheduler"])
         return {"optimizer": optimizer,
                 "lr_scheduler": {"scheduler": scheduler, "interval": "epoch", "frequency": 1}}

@@ -150,3 +150,29 @@ def test_conditional_synthesis_signature_is_the_reference_one():
     assert list(inspect.signature(unconditional_synthesis).parameters)[:3] == ["vae_model", "num_samples", "device"]
     with pytest.raises(RuntimeError, match="GPU only"):
         conditional_synthesis(object(), 4, 1)
+
+
+def test_fused_adam_is_a_torch_adam_and_falls_through_on_cpu():
+    """optim.FusedAdam (what configure_optimizers returns, lightning.py:204-205): a torch.optim.Adam subclass whose step() is
+    torch's own whenever the HIP launch does not apply -- on CPU parameters it must reproduce torch.optim.Adam bit for bit,
+    and its state_dict must load into a plain Adam and back"""
+    import torch
+    from pseudo_speaker_vae_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    w0 = [torch.randn(7, 5), torch.randn(5)]
+    pa = [torch.nn.Parameter(w.clone()) for w in w0]
+    pb = [torch.nn.Parameter(w.clone()) for w in w0]
+    oa = FusedAdam(pa, lr=3e-3, weight_decay=0.01)
+    ob = torch.optim.Adam(pb, lr=3e-3, weight_decay=0.01)
+    assert isinstance(oa, torch.optim.Adam)
+    for it in range(3):
+        for p, q in zip(pa, pb):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)
+    ob.load_state_dict(oa.state_dict())
+    oa.load_state_dict(ob.state_dict())
+    assert set(oa.state_dict()["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from helpers import check_masks, masks_of  # noqa: E402
-from helpers import GOLDEN, REL_TOL, assert_close, load
+from helpers import GOLDEN, REL_TOL, assert_close, load, rel_err
 from oracle import psvae_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -930,3 +930,55 @@ def test_general_single_label_cross_entropy_step_matches_oracle(act, C, hidden, 
         assert_close(l.weight.grad.cpu(), 0.7 * gW, REL_TOL, "trunk dW"); assert_close(l.bias.grad.cpu(), 0.7 * gb, REL_TOL, "trunk db")
     assert_close(lins[-1].weight.grad.cpu(), 0.7 * ohg[0][0], REL_TOL, "head dW")
     assert_close(lins[-1].bias.grad.cpu(), 0.7 * ohg[0][1], REL_TOL, "head db")
+
+
+def test_fused_adam_matches_torch_adam_and_exchanges_state():
+    """optim.FusedAdam.step() (one launch over all parameter tensors, psvae_adam_multi_f32) against torch.optim.Adam on the
+    same gradients: weight decay, a learning rate changed between steps, a parameter without a gradient in one step, and a
+    state_dict moved from one to the other in the middle -- what Lightning's checkpoint restore does"""
+    from pseudo_speaker_vae_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(512, 256), (512,), (512, 512), (64, 512), (64,), (3, 7)]
+    w0 = [torch.randn(*s, device=DEV) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(w.clone()) for w in w0]
+    pb = [torch.nn.Parameter(w.clone()) for w in w0]
+    oa = FusedAdam(pa, lr=1e-3, weight_decay=0.02, betas=(0.9, 0.99))
+    ob = torch.optim.Adam(pb, lr=1e-3, weight_decay=0.02, betas=(0.9, 0.99))
+    for it in range(6):
+        for k, (p, q) in enumerate(zip(pa, pb)):
+            if it == 2 and k == 3:          # a tensor without a gradient this step: its step count falls behind
+                p.grad = q.grad = None
+                continue
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        if it == 3:                          # a scheduler's write
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 4e-4
+        if it == 4:                          # a checkpoint taken from one kind and restored into the other
+            sa, sb = oa.state_dict(), ob.state_dict()
+            oa.load_state_dict(sb)
+            ob.load_state_dict(sa)
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    for k, (p, q) in enumerate(zip(pa, pb)):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-6, f"tensor {k}: {rel_err(p.detach().cpu(), q.detach().cpu()):.2e}"
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"])
+        assert rel_err(oa.state[p]["exp_avg_sq"].cpu(), ob.state[q]["exp_avg_sq"].cpu()) < 2e-6
+
+
+def test_configure_optimizers_returns_the_fused_adam_and_it_trains():
+    from pseudo_speaker_vae_amd.lightning import PseudoSpeakerVAE
+    from pseudo_speaker_vae_amd.optim import FusedAdam
+    mod = PseudoSpeakerVAE(model=dict(input_dim=256, latent_dim=64), optimizer=dict(lr=1e-3), scheduler=dict(T_max=10)).to(DEV)
+    cfg = mod.configure_optimizers()
+    opt = cfg["optimizer"]
+    assert isinstance(opt, FusedAdam) and isinstance(opt, torch.optim.Adam) and cfg["lr_scheduler"]["interval"] == "epoch"
+    x = torch.randn(256, 256, device=DEV)
+    first = None
+    for i in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = mod.training_step((x, {}), i)["loss"]
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+    assert float(loss) < first
