@@ -157,15 +157,21 @@ class FusedAdam(torch.optim.Adam):
             c.step += 1
             beta1, beta2 = group["betas"]
             lr, eps, wd = float(group["lr"]), float(group["eps"]), float(group["weight_decay"])
-            if torch.cuda.current_device() != c.device_index:
-                torch.cuda.set_device(c.device_index)
-            stream, o = _ffi.stream_ptr(), 0
-            for pl, arr, P, M, V, N in c.chunks:
-                G = arr(*gptrs[o:o + len(pl)])
-                o += len(pl)
-                _ffi.check(L.psvae_adam_multi_f32(len(pl), P, G, M, V, N, c.step, lr, float(beta1), float(beta2), eps, wd, 1.0,
-                                                  stream), "adam_multi")
+            if torch.cuda.current_device() != c.device_index:  # (a model on another device than the current one: rare)
+                with torch.cuda.device(c.device_index):
+                    self._launch_chunks(L, c, gptrs, lr, beta1, beta2, eps, wd)
+            else:
+                self._launch_chunks(L, c, gptrs, lr, beta1, beta2, eps, wd)
         return loss
+
+    @staticmethod
+    def _launch_chunks(L, c, gptrs, lr, beta1, beta2, eps, wd):
+        stream, o = _ffi.stream_ptr(), 0
+        for pl, arr, P, M, V, N in c.chunks:
+            G = arr(*gptrs[o:o + len(pl)])
+            o += len(pl)
+            _ffi.check(L.psvae_adam_multi_f32(len(pl), P, G, M, V, N, c.step, lr, float(beta1), float(beta2), eps, wd, 1.0, stream),
+                       "adam_multi")
 
     def _general_step(self, L, group):
         """any subset of the group's parameters with gradients, any mix of step counts: one launch per distinct step count;
