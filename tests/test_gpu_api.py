@@ -966,7 +966,8 @@ def test_fused_adam_matches_torch_adam_and_exchanges_state():
         assert rel_err(oa.state[p]["exp_avg_sq"].cpu(), ob.state[q]["exp_avg_sq"].cpu()) < 2e-6
 
 
-def test_configure_optimizers_returns_the_fused_adam_and_it_trains():
+def test_configure_optimizers_returns_the_fused_adam_and_it_trains(monkeypatch):
+    monkeypatch.delenv("PSVAE_FUSED_ADAM", raising=False)
     from pseudo_speaker_vae_amd.lightning import PseudoSpeakerVAE
     from pseudo_speaker_vae_amd.optim import FusedAdam
     mod = PseudoSpeakerVAE(model=dict(input_dim=256, latent_dim=64), optimizer=dict(lr=1e-3), scheduler=dict(T_max=10)).to(DEV)

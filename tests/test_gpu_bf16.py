@@ -302,12 +302,13 @@ def test_bf16_row_chains_are_deterministic_and_row_local():
         assert_close_bf16(((b0 + b1) / 2).cpu(), a.cpu(), "shard mean " + k)
 
 
-def test_bf16_packs_kept_by_the_optimizer_step_equal_packs_rebuilt_in_the_pass():
+def test_bf16_packs_kept_by_the_optimizer_step_equal_packs_rebuilt_in_the_pass(monkeypatch):
     """PSVAE_BF16_PACKS_CURRENT (include/psvae.h): a pass that is told the bf16 weight packs in its scratch are current
     skips the pack launch and gives the SAME bits as a pass that rebuilds them; the engine keeps them current across its
     fused Adam and notices parameters written through torch ops (their version counter)"""
     from pseudo_speaker_vae_amd import _ffi, ops
     from pseudo_speaker_vae_amd.engine import TrainEngine
+    monkeypatch.delenv("PSVAE_BF16_PACK_IN_STEP", raising=False)
     D, Z, B = 256, 64, 640
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, D, generator=g).to(DEV)

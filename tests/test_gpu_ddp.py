@@ -80,10 +80,11 @@ def test_one_rank_rccl_engine_modes_match_the_engine_without_a_group(nccl_group,
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph_then_allreduce"])
-def test_one_rank_rccl_bf16_engine_matches_the_engine_without_a_group(nccl_group, mode):
+def test_one_rank_rccl_bf16_engine_matches_the_engine_without_a_group(nccl_group, mode, monkeypatch):
     """the bf16 pass (row chains, 6 launches with the weight packs kept by the optimizer step) under a process group: same gradients, loss scalars and Philox state as
     without one, eager and captured"""
     from pseudo_speaker_vae_amd.engine import TrainEngine
+    monkeypatch.delenv("PSVAE_BF16_PACK_IN_STEP", raising=False)
     x = torch.randn(B, D, device=DEV)
     kw = dict(device=DEV, seed=9, beta=0.6, dtype="bf16", conditional=True)
     ref = TrainEngine(D, Z, B, **kw)
