@@ -104,6 +104,11 @@ size_t psvae_scratch_bytes(const psvae_dims* dims);
 /* Test hook for the epsilon generator: n standard normals, Philox4x32-10 + Box-Muller; element e
  * comes from Philox block (offset + e/4), key = seed.  Replaces torch.randn_like (model.py:57). */
 int psvae_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* The same Philox blocks through Box-Muller on the hardware transcendental instructions (v_log_f32, v_sqrt_f32, v_sin_f32 /
+ * v_cos_f32 in revolutions): within 2e-6 of the largest |value| of the stream above, straight-line code.  This is, bit for
+ * bit, the noise the Langevin samplers (psvae_langevin_*) and the z of psvae_sample_decode_* draw inside their kernels --
+ * what a test injects to reproduce them. */
+int psvae_philox_normal_fast_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
 /* VAEModel.forward (model.py:38-63).  eps_in != NULL injects the normal draw (parity tests);
  * eps_in == NULL draws it from Philox(seed, offset) -- either way it is written to acts->eps.
@@ -267,7 +272,8 @@ int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, in
  * single-label ReLU LatentClassifier with one hidden layer (hidden = its width <= 128, W1[hidden,Z], W2[C,hidden];
  * latent_classifier.py:30-40) or a single Linear (hidden = 0, W1[C,Z]).  z[N,Z] is updated in place over
  * num_steps steps:  z += 0.5 s^2 grad(log p(y=target|z) - 0.5|z|^2) + s w noise.  noises (nullable, [T,N,Z])
- * injects the per-step normals (parity tests), else they come from Philox(seed, offset + t*ceil(N*Z/4) + ..);
+ * injects the per-step normals (parity tests), else they come from Philox(seed, offset + t*ceil(N*Z/4) + ..) as
+ * psvae_philox_normal_fast_f32 writes them;
  * history (nullable, [T,N,Z]) receives z after every step.  Z in {16,32,64,128}, C <= 8. */
 int psvae_langevin_f32(int64_t N, int64_t Z, int64_t hidden, int64_t C, const float* W1, const float* b1,
                        const float* W2, const float* b2, float* z, int32_t target, float step_size,

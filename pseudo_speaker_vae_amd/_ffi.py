@@ -30,7 +30,7 @@ SYMBOLS = (
     "psvae_forward_f32", "psvae_elbo_f32", "psvae_backward_f32", "psvae_train_step_f32",
     "psvae_tune_train_step_f32", "psvae_describe_plan", "psvae_set_plan",
     "psvae_classifier_scratch_bytes", "psvae_classifier_ce_f32", "psvae_consistency_scratch_bytes", "psvae_consistency_ce_f32", "psvae_decode_bf16_scratch_bytes", "psvae_decode_bf16", "psvae_forward_bf16", "psvae_backward_bf16",
-    "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_pack_params_bf16", "psvae_adam_multi_f32", "psvae_wgrad_bf16_scratch_bytes", "psvae_wgrad_bf16", "psvae_decode_scratch_bytes",
+    "psvae_bf16_scratch_bytes", "psvae_train_step_bf16", "psvae_pack_params_bf16", "psvae_philox_normal_fast_f32", "psvae_adam_multi_f32", "psvae_wgrad_bf16_scratch_bytes", "psvae_wgrad_bf16", "psvae_decode_scratch_bytes",
     "psvae_decode_f32", "psvae_gemm_f32", "psvae_langevin_f32", "psvae_gather_rows_f32", "psvae_adam_step_f32",
     "psvae_last_step_launches", "psvae_transpose_params_f32", "psvae_adam_step_dev_f32", "psvae_elbo_grad_f32",
     "psvae_last_decode_launches", "psvae_last_step_launches_bf16", "psvae_sample_decode_f32", "psvae_sample_decode_bf16",
@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
     L.psvae_decode_scratch_bytes.argtypes = [C.c_int64]
     vp, u64, i64, u32, f32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_float
     L.psvae_philox_normal_f32.argtypes = [vp, i64, u64, u64, vp]
+    L.psvae_philox_normal_fast_f32.argtypes = [vp, i64, u64, u64, vp]
+    L.psvae_philox_normal_fast_f32.restype = C.c_int
     L.psvae_forward_f32.argtypes = [C.POINTER(Dims), vp, C.POINTER(Params), C.POINTER(Cond), vp, u64, u64, vp,
                                     C.POINTER(Acts), vp, vp, vp, vp, u32, vp]
     L.psvae_elbo_f32.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, f32, vp, vp, u32, vp]

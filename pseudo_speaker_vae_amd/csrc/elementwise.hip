@@ -39,6 +39,23 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ 
     }
 }
 
+// the same blocks through Box-Muller on the hardware transcendentals (philox_normal4_hw): what the Langevin chains and the
+// fused decode kernels draw inside their loops
+__global__ __launch_bounds__(256) void philox_normal_fast_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                                 uint64_t offset) {
+    const int64_t nblk = (n + 3) / 4;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = philox_normal4_hw(offset + (uint64_t)b, seed);
+        const int64_t e = 4 * b;
+        if (e + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+            *reinterpret_cast<f32x4*>(out + e) = v;
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (e + i < n) out[e + i] = v[i];
+        }
+    }
+}
+
 static inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -49,6 +66,12 @@ static inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
 hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, out, n, seed, offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_philox_normal_fast(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(philox_normal_fast_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, out, n, seed, offset);
     return hipGetLastError();
 }
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void langevin_general_kernel(int64_t N, int hi
         for (int k = 0; k < ZD; k += 4) {
             f32x4 nz;
             if (noises) nz = *reinterpret_cast<const f32x4*>(noises + ((size_t)t * N + rr) * ZD + k);
-            else nz = philox_normal4(offset + (uint64_t)t * blocks_per_step + (uint64_t)((rr * ZD + k) >> 2), seed);
+            else nz = philox_normal4_hw(offset + (uint64_t)t * blocks_per_step + (uint64_t)((rr * ZD + k) >> 2), seed);
             z[k] += drift * gz[k] + nsc * nz[0];
             z[k + 1] += drift * gz[k + 1] + nsc * nz[1];
             z[k + 2] += drift * gz[k + 2] + nsc * nz[2];

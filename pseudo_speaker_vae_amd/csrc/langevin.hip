@@ -17,6 +17,7 @@
 //   z     += 0.5 s^2 grad + s w noise                                              (inference.py:97)
 
 #include "psvae_common.h"
+#include "psvae_device.h"
 
 namespace psvae {
 
@@ -31,7 +32,13 @@ __device__ __forceinline__ void philox4(uint64_t blk, uint64_t seed, uint32_t (&
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// The chain's noise: Philox4x32-10 blocks (the VAE's epsilon stream) through Box-Muller on the HARDWARE transcendentals
+// (v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, psvae_device.h philox_normal4_hw) -- what psvae_philox_normal_fast_f32 writes,
+// bit for bit.  With libm's logf / sincosf the chain on the matrix cores was bound by the vector ALU's issue port, not by its
+// MFMAs: 6.9 vector instructions per MFMA (rocprofv3: SQ_INSTS_VALU 10.96 G against SQ_INSTS_MFMA 1.6 G per 1 M rows x 100
+// steps), about 1,000 of a step's 1,750 in the noise.
 __device__ __forceinline__ f32x4 normal4(uint64_t blk, uint64_t seed) {
+#ifdef PSVAE_LANGEVIN_EXACT_NOISE  // (the libm form, for A/B runs)
     uint32_t r[4];
     philox4(blk, seed, r);
     constexpr float S = 5.9604644775390625e-08f, TWO_PI = 6.283185307179586f;
@@ -42,6 +49,9 @@ __device__ __forceinline__ f32x4 normal4(uint64_t blk, uint64_t seed) {
     sincosf(TWO_PI * u1, &sa, &ca);
     sincosf(TWO_PI * u3, &sb, &cb);
     return f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
+#else
+    return philox_normal4_hw(blk, seed);
+#endif
 }
 
 constexpr int LV_MAXC = 8;

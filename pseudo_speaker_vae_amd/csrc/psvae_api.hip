@@ -212,6 +212,13 @@ int psvae_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t offse
     return 0;
 }
 
+int psvae_philox_normal_fast_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out) return PSVAE_ERR_NULL;
+    if (n < 0) return PSVAE_ERR_SHAPE;
+    RET_IF(launch_philox_normal_fast(out, n, seed, offset, (hipStream_t)stream));
+    return 0;
+}
+
 int psvae_gemm_f32(int kind, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                    int64_t ldb, float* C, int64_t ldc, const float* bias_or_mask, float* colsum, int epi, int tile,
                    void* stream) {

@@ -178,6 +178,7 @@ hipError_t launch_cond_colsum_bf16(const unsigned short* const* dY, float* const
 
 // ---- elementwise / row kernels (elementwise.hip) ------------------------------------------------
 hipError_t launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+hipError_t launch_philox_normal_fast(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 // z = mu + exp(0.5 lv) * eps ; eps from eps_in or Philox; writes eps_out, z
 // rng (nullable, device {seed, offset}) overrides seed/offset and is advanced by ceil(n/4) afterwards
 hipError_t launch_reparam(const float* mu, const float* lv, const float* eps_in, uint64_t seed,

@@ -31,9 +31,12 @@ def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def philox_normal(n: int, seed: int, offset: int, device) -> torch.Tensor:
+def philox_normal(n: int, seed: int, offset: int, device, fast: bool = False) -> torch.Tensor:
+    """n standard normals of the Philox stream (seed, offset); fast: Box-Muller on the hardware transcendentals
+    (psvae_philox_normal_fast_f32) -- the form the Langevin chains and the fused decode kernels draw inside their loops"""
     out = torch.empty(n, dtype=torch.float32, device=device)
-    _ffi.check(_ffi.lib().psvae_philox_normal_f32(_ffi.ptr(out), n, seed, offset, _ffi.stream_ptr()), "philox_normal")
+    fn = _ffi.lib().psvae_philox_normal_fast_f32 if fast else _ffi.lib().psvae_philox_normal_f32
+    _ffi.check(fn(_ffi.ptr(out), n, seed, offset, _ffi.stream_ptr()), "philox_normal")
     return out
 
 

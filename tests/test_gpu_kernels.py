@@ -117,3 +117,19 @@ def test_adam_matches_oracle(ops):
         pc, mc, vc = O.adam_step(pc, 0.5 * g, mc, vc, step, 1e-3, weight_decay=0.01)
     assert_close(p.cpu(), pc, 1e-6, "adam param")
     assert_close(v.cpu(), vc, 1e-6, "adam v")
+
+
+def test_philox_fast_stream_is_the_exact_stream_to_hardware_accuracy():
+    DEV = "cuda:0"
+    """psvae_philox_normal_fast_f32 (Box-Muller on v_log / v_sqrt / v_sin / v_cos): the same Philox blocks as
+    psvae_philox_normal_f32, every value within 2e-6 of the stream's largest magnitude; standard-normal moments; and what
+    the samplers draw inside their kernels (tests/test_gpu_properties.py, test_gpu_decode_fused.py inject it bit for bit)"""
+    from pseudo_speaker_vae_amd import ops
+    n = 1 << 20
+    a = ops.philox_normal(n, 77, 1234, DEV).cpu().double()
+    b = ops.philox_normal(n, 77, 1234, DEV, fast=True).cpu().double()
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    assert abs(float(b.mean())) < 4e-3 and abs(float(b.var()) - 1.0) < 6e-3
+    assert abs(float((b ** 4).mean()) - 3.0) < 5e-2
+    odd = ops.philox_normal(1001, 77, 1234, DEV, fast=True).cpu().double()   # ragged tail, same values
+    assert torch.equal(odd, b[:1001])
