@@ -20,6 +20,11 @@ ARCH = "gfx950"
 
 # kernels whose inline-asm register loads must never be spilled (hipcc would store the destination register before the
 # data has landed and reload garbage): file -> substring of the mangled kernel names
+# per-file compiler flags.  langevin.hip: no SLP vectorisation -- under plain -O3 hipcc packs adjacent scalar fp32 adds / muls into
+# v_pk_* instructions, which cost the chain's MFMA loop time beside the MFMAs (cdna guide; measured 40.6 -> 40.1 ms per
+# 1 M rows x 100 steps)
+EXTRA_FLAGS = {"langevin.hip": ["-fno-slp-vectorize"]}
+
 NO_SPILL = {}  # (none at present: the bf16 decode kernel that needed it was replaced by one without asm loads)
 
 
@@ -57,6 +62,7 @@ def _src_hash() -> str:
     for d in deps:
         h.update(os.path.basename(d).encode())
         h.update(open(d, "rb").read())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -76,7 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = common + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src in NO_SPILL:  # resource remarks on stderr, checked below
             cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
