@@ -23,7 +23,8 @@ ARCH = "gfx950"
 # per-file compiler flags.  langevin.hip: no SLP vectorisation -- under plain -O3 hipcc packs adjacent scalar fp32 adds / muls into
 # v_pk_* instructions, which cost the chain's MFMA loop time beside the MFMAs (cdna guide; measured 40.6 -> 40.1 ms per
 # 1 M rows x 100 steps)
-EXTRA_FLAGS = {"langevin.hip": ["-fno-slp-vectorize"]}
+# gemm_f32.hip: the same for the epilogues beside the fp32 MFMA loops (cfg2 step 128.4 -> 127.5 us, three interleaved runs)
+EXTRA_FLAGS = {"langevin.hip": ["-fno-slp-vectorize"], "gemm_f32.hip": ["-fno-slp-vectorize"]}
 
 NO_SPILL = {}  # (none at present: the bf16 decode kernel that needed it was replaced by one without asm loads)
 
