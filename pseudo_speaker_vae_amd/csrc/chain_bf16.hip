@@ -26,7 +26,8 @@
 #include "psvae_device.h"
 
 #ifndef PSVAE_CHAIN_NA
-#define PSVAE_CHAIN_NA 3  // ring depth of the weight fragments at 32-row tiles: 3 / 4 / 5 measured 121.6 / 122.0 / 121.7 us per cfg3 step
+#define PSVAE_CHAIN_NA 4  // ring depth of the weight fragments at 16- / 32-row tiles: 2 / 3 / 4 / 5 measured 96.0 / 94.7 / 94.1 / 94.5 us per
+                          // cfg3 step (round 2, 32-row tiles everywhere: 3 / 4 / 5 = 121.6 / 122.0 / 121.7)
 #endif
 
 namespace psvae {
