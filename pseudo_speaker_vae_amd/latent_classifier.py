@@ -276,8 +276,32 @@ class LatentClassifier(nn.Module):
         return _ClassifierCEFunction.apply(z, y, hidden, *params)
 
     def forward(self, x):
+        fast = self._hip_forward(x)
+        if fast is not None:
+            return fast
         for layer in self.layers:
             x = layer(x)
         if self.single_label_mode:
             return x
         return {label: head(x) for label, head in self.output_layers.items()}
+
+    def _hip_forward(self, x):
+        """inference (gradients off, fp32 GPU tensors, ReLU stacks): the layers as MFMA GEMM launches with fused bias /
+        bias + ReLU epilogues (ops.mlp_forward) instead of ATen; anything else returns None and forward() runs as written"""
+        from . import ops
+        mods = list(self.layers)
+        lins = [m for m in mods if isinstance(m, nn.Linear)]
+        heads = [] if self.single_label_mode else list(self.output_layers.values())
+        if any(not isinstance(m, (nn.Linear, nn.ReLU)) for m in mods) or not ops.mlp_forward_ok(x, lins + heads):
+            return None
+        stack, i = [], 0
+        while i < len(mods):  # (Linear [, ReLU]) pairs, in order
+            if not isinstance(mods[i], nn.Linear):
+                return None
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            stack.append((mods[i].weight, mods[i].bias, relu))
+            i += 2 if relu else 1
+        h = ops.mlp_forward(x, stack) if stack else x
+        if self.single_label_mode:
+            return h
+        return {label: ops.mlp_forward(h, [(head.weight, head.bias, False)]) for label, head in self.output_layers.items()}

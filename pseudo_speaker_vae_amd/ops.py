@@ -61,6 +61,24 @@ def gemm(kind: int, A: torch.Tensor, B: torch.Tensor, epi: int = EPI_NONE, aux: 
     return (Cm, cs) if want_colsum else Cm
 
 
+def mlp_forward(x: torch.Tensor, layers) -> torch.Tensor:
+    """y = Linear_n(... relu(Linear_1(x))) on the MFMA GEMM with fused bias / bias + ReLU epilogues, one launch per layer:
+    `layers` = [(weight [out, in], bias [out], relu: bool), ...].  Inference only (no autograd): what the classifier heads'
+    forward() takes when gradients are off (latent_classifier.py:55-70, embedding_classifier.py:49-62)."""
+    h = _f32(x, "x")
+    for W, b, relu in layers:
+        h = gemm(GEMM_NT, h, W.detach(), EPI_BIAS_RELU if relu else EPI_BIAS, aux=_f32(b.detach(), "bias"))
+    return h
+
+
+def mlp_forward_ok(x: torch.Tensor, linears) -> bool:
+    """whether mlp_forward applies: a 2-D fp32 CUDA batch, fp32 CUDA Linear layers, gradients not being recorded"""
+    if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in linears)):
+        return False
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0
+            and all(l.weight.is_cuda and l.weight.dtype == torch.float32 and l.bias is not None for l in linears))
+
+
 class Workspace:
     """Caller-owned buffers of one batch shape: saved activations, outputs, scratch, gradients."""
 

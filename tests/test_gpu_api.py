@@ -983,3 +983,31 @@ def test_configure_optimizers_returns_the_fused_adam_and_it_trains(monkeypatch):
         opt.step()
         first = float(loss) if first is None else first
     assert float(loss) < first
+
+
+@pytest.mark.parametrize("kind", ["latent-2-layer", "latent-1-layer", "latent-3-layer", "latent-multilabel", "embedding"])
+def test_classifier_heads_forward_on_hip_when_gradients_are_off(kind):
+    """LatentClassifier.forward (latent_classifier.py:55-70, called by inference.py:80) and EmbeddingClassifier.forward
+    (embedding_classifier.py:49-62) at inference: MFMA GEMM launches with fused bias / ReLU epilogues, equal to the same
+    module's ATen forward; with gradients on, or a tanh trunk, forward() stays the autograd-connected ATen path"""
+    from pseudo_speaker_vae_amd.embedding_classifier import EmbeddingClassifier
+    from pseudo_speaker_vae_amd.latent_classifier import LatentClassifier
+    torch.manual_seed(3)
+    if kind == "embedding":
+        m, x = EmbeddingClassifier(256, 3, hidden_dim=128).to(DEV), torch.randn(333, 256, device=DEV)
+    elif kind == "latent-multilabel":
+        m, x = LatentClassifier(64, {"gender": 3, "age": 5}, num_layers=2, hidden_dim=96).to(DEV), torch.randn(257, 64, device=DEV)
+    else:
+        layers = {"latent-1-layer": 1, "latent-2-layer": 2, "latent-3-layer": 3}[kind]
+        m, x = LatentClassifier(64, 3, num_layers=layers, hidden_dim=128).to(DEV), torch.randn(1000, 64, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        fast = m(x)
+    ref = m(x.clone().requires_grad_(True))  # gradients on: the ATen path
+    pairs = [(fast[k], ref[k]) for k in fast] if isinstance(fast, dict) else [(fast, ref)]
+    for a, b in pairs:
+        assert b.requires_grad and not a.requires_grad
+        assert_close(a.cpu(), b.detach().cpu(), 2e-5, kind)
+    t = LatentClassifier(64, 3, num_layers=2, hidden_dim=32, activation="tanh").to(DEV)
+    with torch.no_grad():
+        assert t._hip_forward(x[:, :64] if x.shape[1] > 64 else x) is None
