@@ -105,9 +105,10 @@ size_t psvae_scratch_bytes(const psvae_dims* dims);
  * comes from Philox block (offset + e/4), key = seed.  Replaces torch.randn_like (model.py:57). */
 int psvae_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 /* The same Philox blocks through Box-Muller on the hardware transcendental instructions (v_log_f32, v_sqrt_f32, v_sin_f32 /
- * v_cos_f32 in revolutions): within 2e-6 of the largest |value| of the stream above, straight-line code.  This is, bit for
- * bit, the noise the Langevin samplers (psvae_langevin_*) and the z of psvae_sample_decode_* draw inside their kernels --
- * what a test injects to reproduce them. */
+ * v_cos_f32 in revolutions): straight-line code, within 2e-6 absolute of the stream above (measured: 1.8e-6 over 4 M
+ * normals).  This is, bit for bit, what every kernel that draws INSIDE its work produces -- the epsilon of the training passes
+ * (psvae_forward_* / psvae_train_step_* with eps_in == NULL), the noise of the Langevin samplers, the z of
+ * psvae_sample_decode_* -- and what a test injects to reproduce them. */
 int psvae_philox_normal_fast_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
 /* VAEModel.forward (model.py:38-63).  eps_in != NULL injects the normal draw (parity tests);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ 
                                                             uint64_t offset) {
     const int64_t nblk = (n + 3) / 4;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = philox_normal4(offset + (uint64_t)b, seed);
+        const f32x4 v = philox_normal4_exact(offset + (uint64_t)b, seed);
         const int64_t e = 4 * b;
         if (e + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
             *reinterpret_cast<f32x4*>(out + e) = v;

@@ -260,8 +260,9 @@ def test_bf16_pass_draws_the_same_philox_epsilon_as_the_fp32_path(B):
     ops.train_step_bf16(ws, x, params, grads, loss3, rng_state=state)
     torch.cuda.synchronize()
     assert ops.last_step_launches_bf16() in (6, 7)  # (no slab sums where the batch is one slice)
-    ref = ops.philox_normal(B * Z, 1234, 777, DEV).view(B, Z)
+    ref = ops.philox_normal(B * Z, 1234, 777, DEV, fast=True).view(B, Z)  # (the in-kernel form of the stream: psvae.h)
     assert torch.equal(ws.eps, ref)
+    assert_close(ws.eps.cpu(), torch.from_numpy(O.philox_normal(B * Z, 1234, 777).reshape(B, Z)), 1e-5, "epsilon vs the oracle's stream")
     assert int(state[1]) == 777 + B * Z // 4 and int(state[0]) == 1234
     z = ws.mu + torch.exp(0.5 * ws.logvar) * ws.eps
     assert_close(ws.z.cpu(), z.cpu(), 1e-6, "z = mu + exp(logvar / 2) eps")
