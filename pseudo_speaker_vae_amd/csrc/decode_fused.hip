@@ -341,14 +341,19 @@ __global__ __launch_bounds__(256) void pack_decode_weights_bf16w_kernel(const fl
     }
 }
 
-template <int ZK, int DBW, bool DRAW = false>  // Z = 32 ZK, D = 64 DBW, hidden = 512; DRAW: z comes from Philox, not memory
-__global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFusedBfArgs a) {
+// RGD: row groups of 16 per tile -- 8 (128 rows: one workgroup per CU) or 4 (64 rows: a 64 KB image, two workgroups per CU;
+// one's publishes and stores then run under the other's MFMAs, at twice the weight intake per row)
+template <int ZK, int DBW, bool DRAW = false, int RGD = 8>  // Z = 32 ZK, D = 64 DBW, hidden = 512; DRAW: z comes from Philox, not memory
+__global__ __launch_bounds__(256, RGD == 4 ? 2 : 1) void decode_rows_bf16_kernel(const DecodeFusedBfArgs a) {
+    static_assert(RGD == 8 || RGD == 4, "128- or 64-row tiles");
+    constexpr int TR = 16 * RGD;                     // rows per tile
+    constexpr int RGW = RGD / 4;                     // row groups whose latent rows a wavefront loads / draws
     constexpr int HK = H / 32;                       // 16 k steps of a hidden input
     constexpr int S = ZK + HK + HK;                  // k steps of the whole weight stream per tile
-    constexpr int NA = 3;                            // weight-fragment ring: this step and two ahead
-    constexpr int RPP = DBW == 8 ? 64 : 128;         // rows per x_hat staging pass (D = 512: two passes)
+    constexpr int NA = RGD == 8 ? 3 : 2;             // weight-fragment ring: this step and two (one: 64-row tiles, 256 registers) ahead
+    constexpr int RPP = DBW == 8 ? TR / 2 : TR;      // rows per x_hat staging pass (D = 512: two passes)
     constexpr int RS = 256 * DBW + 16;               // bytes of a staged row
-    constexpr int IMG = RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024;
+    constexpr int IMG = RPP * RS > TR * 1024 ? RPP * RS : TR * 1024;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* act = reinterpret_cast<char*>(lds);        // [16 k steps][8 row groups][64 lanes][16 B] = 128 KB; x_hat staging
     float* sbias = lds + IMG / 4;                    // [512 + 512 + D]
@@ -378,19 +383,19 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
             if (mi < mb_of(s)) wa[s % NA][mi] = *(gbf16x8*)(wsrc + mi * 512);
         wsrc += mb_of(s) * 512;
     };
-    bf16x8 bb[2][8];
-    auto bfetch = [&](int set, int kb) {  // B fragments of k step kb: all 8 row groups
-        const char* src = act + kb * 8192 + lane * 16;
+    bf16x8 bb[2][RGD];
+    auto bfetch = [&](int set, int kb) {  // B fragments of k step kb: all row groups
+        const char* src = act + kb * (RGD * 1024) + lane * 16;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
+        for (int g = 0; g < RGD; ++g) bb[set][g] = *reinterpret_cast<const bf16x8*>(src + 1024 * g);
     };
 
-    const long ntiles = (a.N + 127) / 128;
-    f32x4 zn[2][ZK][2];  // the next tile's latent rows of this wavefront's two row groups (fp32)
+    const long ntiles = (a.N + TR - 1) / TR;
+    f32x4 zn[RGW][ZK][2];  // the next tile's latent rows of this wavefront's row groups (fp32)
     auto zfetch = [&](long tile) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            long row = tile * 128 + 32 * wave + 16 * g + r;
+        for (int g = 0; g < RGW; ++g) {
+            long row = tile * TR + 16 * RGW * wave + 16 * g + r;
             row = row < a.N ? row : a.N - 1;
             const float* zp = a.z + row * a.Z + 4 * q;
 #pragma unroll
@@ -407,26 +412,23 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
     auto zpiece = [&](long tile, auto Pc) {
         constexpr int p = decltype(Pc)::value;
         constexpr int g = p / (2 * ZK), kbz = (p % (2 * ZK)) / 2, h = p % 2;
-        const long row = tile * 128 + 32 * wave + 16 * g + r;
+        const long row = tile * TR + 16 * RGW * wave + 16 * g + r;
         const unsigned long long e = (unsigned long long)(row < a.N ? row : a.N - 1) * a.Z + 32 * kbz + 16 * h + 4 * q;
         zn[g][kbz][h] = philox_normal4_hw(a.offset + (e >> 2), a.seed);
         if (a.z_out && row < a.N) *reinterpret_cast<f32x4*>(a.z_out + e) = zn[g][kbz][h];
     };
+    constexpr int NPZ = 2 * RGW * ZK;  // pieces (Philox blocks) per lane and tile: at most 16
     if constexpr (DRAW) {
-        zpiece(blockIdx.x, std::integral_constant<int, 0>{});
-        if constexpr (ZK >= 1) { zpiece(blockIdx.x, std::integral_constant<int, 1>{}); zpiece(blockIdx.x, std::integral_constant<int, 2>{}); zpiece(blockIdx.x, std::integral_constant<int, 3>{}); }
-        if constexpr (ZK >= 2) { zpiece(blockIdx.x, std::integral_constant<int, 4>{}); zpiece(blockIdx.x, std::integral_constant<int, 5>{}); zpiece(blockIdx.x, std::integral_constant<int, 6>{}); zpiece(blockIdx.x, std::integral_constant<int, 7>{}); }
-        if constexpr (ZK >= 4) {
-            zpiece(blockIdx.x, std::integral_constant<int, 8>{}); zpiece(blockIdx.x, std::integral_constant<int, 9>{});
-            zpiece(blockIdx.x, std::integral_constant<int, 10>{}); zpiece(blockIdx.x, std::integral_constant<int, 11>{});
-            zpiece(blockIdx.x, std::integral_constant<int, 12>{}); zpiece(blockIdx.x, std::integral_constant<int, 13>{});
-            zpiece(blockIdx.x, std::integral_constant<int, 14>{}); zpiece(blockIdx.x, std::integral_constant<int, 15>{});
-        }
+#define PSVAE_ZP0(P) if constexpr (P < NPZ) zpiece(blockIdx.x, std::integral_constant<int, (P < NPZ ? P : 0)>{})
+        PSVAE_ZP0(0); PSVAE_ZP0(1); PSVAE_ZP0(2); PSVAE_ZP0(3); PSVAE_ZP0(4); PSVAE_ZP0(5); PSVAE_ZP0(6); PSVAE_ZP0(7);
+        PSVAE_ZP0(8); PSVAE_ZP0(9); PSVAE_ZP0(10); PSVAE_ZP0(11); PSVAE_ZP0(12); PSVAE_ZP0(13); PSVAE_ZP0(14); PSVAE_ZP0(15);
+#undef PSVAE_ZP0
     } else {
         zfetch(blockIdx.x);
     }
-    wfetch(0);
-    wfetch(1);
+    constexpr int PD = NA - 1;  // k steps of weight fragments in flight ahead of the MFMAs
+#pragma unroll
+    for (int i = 0; i < PD; ++i) wfetch(i);
     __syncthreads();  // sbias
 #ifdef PSVAE_STAMP
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -439,13 +441,13 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
         // ---- the tile's latent rows -> B image (k steps 0 .. ZK-1 of `act`); every wavefront is past the previous tile's
         //      last read of `act` (barrier at the end of the loop body)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < RGW; ++g)
 #pragma unroll
             for (int kb = 0; kb < ZK; ++kb)
-                *reinterpret_cast<bf16x8*>(act + (kb * 8 + 2 * wave + g) * 1024 + lane * 16) =
+                *reinterpret_cast<bf16x8*>(act + (kb * RGD + RGW * wave + g) * 1024 + lane * 16) =
                     pack_bf16x8<false>(zn[g][kb][0], zn[g][kb][1]);
         __syncthreads();
-        f32x4 acc[8][8];  // [block of this wavefront][row group]
+        f32x4 acc[8][RGD];  // [block of this wavefront][row group]
         int s = 0;        // k step of the weight stream
         // one layer: KB k steps over MB blocks x 8 row groups; the bias is the first step's C operand
         auto layer = [&](auto KBc, auto MBc, const float* bias, auto between) {
@@ -459,15 +461,15 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
                 __builtin_amdgcn_sched_barrier(0);  // (keeps the compiler from hoisting every step's loads to the top)
                 // the stream is cyclic (the tile's last two steps fetch the next tile's first two) when the ring closes,
                 // S % NA == 0; otherwise those two fetches wait until the tile's last MFMA has issued (below)
-                if (s + 2 < S) wfetch(s + 2);
-                else if (S % NA == 0) wfetch(s + 2 - S);
+                if (s + PD < S) wfetch(s + PD);
+                else if (S % NA == 0) wfetch(s + PD - S);
                 if (kb + 1 < KB) bfetch((kb + 1) & 1, kb + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 between(kb);  // (vector-ALU work the scheduler may interleave with this step's MFMAs)
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-                    for (int g = 0; g < 8; ++g)
+                    for (int g = 0; g < RGD; ++g)
                         acc[mi][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % NA][mi], bb[kb & 1][g],
                                                                             kb == 0 ? bv[mi] : acc[mi][g], 0, 0, 0);
             }
@@ -479,13 +481,13 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
             __syncthreads();  // every wavefront has read the previous image
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 t[8];  // (eight independent convert chains, then their writes: one chain at a time is latency-bound)
+                bf16x8 t[RGD];  // (independent convert chains, then their writes: one chain at a time is latency-bound)
 #pragma unroll
-                for (int g = 0; g < 8; ++g) t[g] = pack_bf16x8<true>(acc[2 * kk][g], acc[2 * kk + 1][g]);
+                for (int g = 0; g < RGD; ++g) t[g] = pack_bf16x8<true>(acc[2 * kk][g], acc[2 * kk + 1][g]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    *reinterpret_cast<bf16x8*>(act + ((4 * wave + kk) * 8 + g) * 1024 + lane * 16) = t[g];
+                for (int g = 0; g < RGD; ++g)
+                    *reinterpret_cast<bf16x8*>(act + ((4 * wave + kk) * RGD + g) * 1024 + lane * 16) = t[g];
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
             const long nxt = tile + gridDim.x;
             layer(std::integral_constant<int, HK>{}, std::integral_constant<int, DBW>{}, sbias + 2 * H, [&](int kb) {
                 // (kb is a constant after unrolling; 4 ZK <= 16 pieces over the 16 k steps)
-#define PSVAE_ZP(P) if (kb == P && P < 4 * ZK) zpiece(nxt, std::integral_constant<int, (P < 4 * ZK ? P : 0)>{})
+#define PSVAE_ZP(P) if (kb == P && P < NPZ) zpiece(nxt, std::integral_constant<int, (P < NPZ ? P : 0)>{})
                 PSVAE_ZP(0); PSVAE_ZP(1); PSVAE_ZP(2); PSVAE_ZP(3); PSVAE_ZP(4); PSVAE_ZP(5); PSVAE_ZP(6); PSVAE_ZP(7);
                 PSVAE_ZP(8); PSVAE_ZP(9); PSVAE_ZP(10); PSVAE_ZP(11); PSVAE_ZP(12); PSVAE_ZP(13); PSVAE_ZP(14); PSVAE_ZP(15);
 #undef PSVAE_ZP
@@ -515,15 +517,15 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
         }
         RSTAMP(6);
         if (S % NA != 0) {  // (their latency runs under the stores, the barrier and the latent rows' write)
-            wfetch(0);
-            wfetch(1);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) wfetch(i);
         }
         // x_hat: a lane holds 4 consecutive features of 16 different rows per block -- stored as it stands, every store
         // instruction would touch 16 rows with 64 bytes each (store-issue bound: 8.8k of the tile's 48k cycles).  The tile goes
         // through LDS instead (the image is dead once every wavefront has left layer 2; rows padded by 16 B so the 16 r lanes
         // hit different banks) and leaves as whole rows: 1 KB contiguous per store instruction.
 #pragma unroll
-        for (int ps = 0; ps < 128 / RPP; ++ps) {
+        for (int ps = 0; ps < TR / RPP; ++ps) {
             __syncthreads();  // image (or the previous pass) no longer read
 #pragma unroll
             for (int g = ps * (RPP / 16); g < (ps + 1) * (RPP / 16); ++g)
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
                     const int it = i0 + i;
                     const int rl = DBW >= 4 ? (RPP / 4) * wave + it / (DBW >= 4 ? DBW / 4 : 1) : (RPP / 4) * wave + 2 * it + (lane >> 5);
                     const int pc = DBW >= 4 ? it % (DBW >= 4 ? DBW / 4 : 1) : 0;
-                    const long row = tile * 128 + ps * RPP + rl;
+                    const long row = tile * TR + ps * RPP + rl;
                     if (row < a.N)
                         *reinterpret_cast<f32x4*>(a.x_hat + row * a.D + pc * 256 + (DBW >= 4 ? lane : (lane & 31)) * 4) = v[i];
                 }
@@ -564,16 +566,17 @@ __global__ __launch_bounds__(256, 1) void decode_rows_bf16_kernel(const DecodeFu
 #endif
 }
 
-template <int ZK, int DBW, bool DRAW>
-static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
-    constexpr int RPP = DBW == 8 ? 64 : 128, RS = 256 * DBW + 16;
-    constexpr size_t lds = (size_t)(RPP * RS > 128 * 1024 ? RPP * RS : 128 * 1024) + (size_t)(2 * H + 64 * DBW) * sizeof(float);
+template <int ZK, int DBW, bool DRAW, int RGD>
+static hipError_t launch_decode_rows_bf16_rg(const DecodeFusedBfArgs& a, hipStream_t s) {
+    constexpr int TR = 16 * RGD, RPP = DBW == 8 ? TR / 2 : TR, RS = 256 * DBW + 16;
+    constexpr size_t lds = (size_t)(RPP * RS > TR * 1024 ? RPP * RS : TR * 1024) + (size_t)(2 * H + 64 * DBW) * sizeof(float);
     static std::atomic<unsigned long long> lds_ok{0};  // per device: psvae_common.h lds_opt_in
-    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW, DRAW>), 160 * 1024))
+    if (hipError_t attr_err = lds_opt_in(lds_ok, reinterpret_cast<const void*>(&decode_rows_bf16_kernel<ZK, DBW, DRAW, RGD>), 160 * 1024))
         return attr_err;
-    const long ntiles = (a.N + 127) / 128;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW, DRAW>), dim3(grid), dim3(256), lds, s, a);
+    const long ntiles = (a.N + TR - 1) / TR;
+    const int slots = 256 * (lds <= 80 * 1024 ? 2 : 1);  // persistent: one workgroup per LDS slot of every CU
+    const int grid = (int)(ntiles < slots ? ntiles : slots);
+    hipLaunchKernelGGL((decode_rows_bf16_kernel<ZK, DBW, DRAW, RGD>), dim3(grid), dim3(256), lds, s, a);
 #ifdef PSVAE_STAMP
     {
         unsigned long long h[8];
@@ -585,6 +588,15 @@ static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStrea
     }
 #endif
     return hipGetLastError();
+}
+
+template <int ZK, int DBW, bool DRAW>
+static hipError_t launch_decode_rows_bf16_t(const DecodeFusedBfArgs& a, hipStream_t s) {
+    // rows per tile / 16: 4 (default: 64-row tiles, two workgroups per CU: 0.82 ms per 1 M rows) or 8 (128-row tiles, one
+    // workgroup per CU, weight ring one k step deeper: 0.85 ms); read per call: a test runs both
+    const char* e = getenv("PSVAE_DECODE_BF16_RG");
+    if (e && atoi(e) == 8) return launch_decode_rows_bf16_rg<ZK, DBW, DRAW, 8>(a, s);
+    return launch_decode_rows_bf16_rg<ZK, DBW, DRAW, 4>(a, s);
 }
 
 hipError_t launch_decode_rows_bf16(int64_t N, int Z, int D, const float* z, const float* const* dec6, float* x_hat,

@@ -135,6 +135,15 @@ def test_fused_bf16_decode_matches_emulation_and_per_layer_path(D, Z, N):
     finally:
         os.environ.pop("PSVAE_DECODE_UNFUSED", None)
     assert not torch.equal(fused, per_layer), "both calls took the same path"
+    # the two tile heights of the fused kernel (64 rows, two workgroups per CU: the default; 128 rows, one): the same
+    # arithmetic per row -- identical bits
+    os.environ["PSVAE_DECODE_BF16_RG"] = "8"
+    try:
+        tall = ops.decode_bf16(z, dec, D)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("PSVAE_DECODE_BF16_RG", None)
+    assert torch.equal(tall, fused), "64-row and 128-row tiles disagree"
     assert_close(fused.cpu(), per_layer.cpu(), BF16_TOL, "fused vs per-layer bf16, all rows", elementwise=False)
     assert float((fused - per_layer).abs().mean() / per_layer.pow(2).mean().sqrt()) < 2e-5
     for lo, hi in ((0, 140), (N // 2 - 3, N // 2 + 130), (N - 150, N)):  # incl. the ragged last tile
