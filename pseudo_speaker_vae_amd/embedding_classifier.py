@@ -89,6 +89,10 @@ class EmbeddingClassifier(_Base):
         self.accuracy = _accuracy(task="multiclass", num_classes=self.num_classes)
 
     def configure_optimizers(self):                                        # embedding_classifier.py:39-47
+        import os
+        if os.environ.get("PSVAE_FUSED_ADAM", "1") != "0":                  # a torch.optim.Adam either way (optim.py)
+            from .optim import FusedAdam
+            return FusedAdam(self.parameters(), **self.optimizer_cfg)
         return torch.optim.Adam(self.parameters(), **self.optimizer_cfg)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:                    # embedding_classifier.py:49-62
