@@ -81,6 +81,15 @@ class FusedAdam(torch.optim.Adam):
             self._sync_steps()
         return super().add_param_group(param_group)
 
+    def zero_grad(self, set_to_none: bool = True):
+        """torch's zero_grad(set_to_none=True) -- every parameter's .grad becomes None -- without its profiler scope and per-call
+        bookkeeping (21-28 us of host time per step for 18 tensors against ~3); set_to_none=False is torch's own"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
     def _build_cache(self, group):
         """every parameter of the group has a usable gradient and the same step count: pointer tables for the launches"""
         params = group["params"]
